@@ -1,0 +1,731 @@
+// Host scene model: text scene grammar, OBJ / packed-mesh loading, BVH build + flattening,
+// BMP texture decode, BMP output.  CPU only; produces the flat rt_scene_desc the device
+// upload (and the CPU oracle used by the tests) consume.
+//
+// Behaviour follows the reference's loader so that a scene file means the same thing:
+//   grammar + list order        CR/raytracer.cpp:180-275
+//   material / primitive keys   CR/primitive.cpp:51-70,101-107,151-157,185-190,237-242,260-281,316-332,344-365
+//   light keys + light prims    CR/Light.cpp:16-25,47-52,84-89,101-116
+//   camera keys + basis         CR/camera.cpp:19-33,44-55,61-77
+//   OBJ reader + transform      CR/primitive.cpp:379-471
+//   BVH build                   CR/primitive.cpp:531-616
+//   BMP reader                  CR/bmp.cpp:52-96        BMP writer  CR/BmpSave.cpp:5-44
+#include "rt_amd.h"
+#include "rt_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct V3 {
+    double x = 0, y = 0, z = 0;
+    V3() {}
+    V3(double X, double Y, double Z) : x(X), y(Y), z(Z) {}
+    double operator[](int a) const { return a == 0 ? x : (a == 1 ? y : z); }
+};
+inline V3 operator+(const V3& a, const V3& b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(const V3& a, const V3& b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator*(const V3& a, double k) { return V3(a.x * k, a.y * k, a.z * k); }
+inline V3 operator/(const V3& a, double k) { return V3(a.x / k, a.y / k, a.z / k); }
+inline V3 cross(const V3& a, const V3& b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline double module(const V3& a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+inline V3 unit(const V3& a) { return a / module(a); }
+// CR/vector3.cpp:142-156
+inline V3 vertical(const V3& a) {
+    V3 r = cross(a, V3(0, 0, 1));
+    if (std::fabs(r.x) < RT_EPS && std::fabs(r.y) < RT_EPS && std::fabs(r.z) < RT_EPS) return V3(1, 0, 0);
+    return unit(r);
+}
+inline rt_vec3 pod(const V3& a) { return rt_vec3{a.x, a.y, a.z}; }
+inline void read_v3(std::stringstream& s, V3& v) { s >> v.x >> v.y >> v.z; }
+
+struct Tri {
+    V3 O1, O2, O3;
+    uint32_t face;
+};
+
+struct HostMesh {
+    std::vector<Tri> tris;
+    V3 vmin{RT_BIG_DIST, RT_BIG_DIST, RT_BIG_DIST}, vmax{-RT_BIG_DIST, -RT_BIG_DIST, -RT_BIG_DIST};
+};
+
+struct HostPrim {
+    int type = -1;
+    bool is_light = false;
+    rt_material mat{};
+    // union of every primitive's fields; unused ones stay zero
+    V3 O, De{0, 0, 1}, Dc{0, 1, 0}, N, Dx, Dy, O1, O2, O3, Nx, Ny, scale, rotation;
+    double R = 0, R_c = 0;
+    int degree = -1;
+    std::vector<double> bzR, bzZ;
+    int mesh = -1;
+    HostPrim() {
+        mat.texture = -1;
+    }
+};
+
+struct HostLight {
+    int type = -1;
+    V3 color, O, Dx, Dy;
+    double R = 0;
+    int light_primitive = -1;
+};
+
+}  // namespace
+
+struct rt_host_scene {
+    rt_scene_desc desc{};
+    std::vector<rt_light> lights;
+    std::vector<rt_primitive> prims;
+    std::vector<rt_texture> textures;
+    std::vector<std::vector<uint8_t>> texture_data;
+    std::vector<rt_mesh> meshes;
+    std::vector<rt_bvh_node> nodes;
+    std::vector<rt_bvh_leaf> leaves;
+    std::string asset_dir;
+    std::vector<std::string> warnings;
+};
+
+namespace {
+
+std::string resolve(const rt_host_scene& hs, const std::string& file) {
+    if (file.empty() || file[0] == '/' || hs.asset_dir.empty()) return file;
+    return hs.asset_dir + "/" + file;
+}
+
+// ---- BMP texture (CR/bmp.cpp:52-96).  The reader takes the pixel rows straight after the
+// 54 header bytes whatever bfOffBits says, as the reference does. ---------------------------
+int load_texture(rt_host_scene& hs, const std::string& file) {
+    std::string path = resolve(hs, file);
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) {
+        hs.warnings.push_back("texture not found, primitive left untextured: " + path);
+        return -1;
+    }
+    unsigned char hdr[54];
+    if (std::fread(hdr, 1, 54, f) != 54 || hdr[0] != 'B' || hdr[1] != 'M') {
+        std::fclose(f);
+        hs.warnings.push_back("not a BMP file, primitive left untextured: " + path);
+        return -1;
+    }
+    auto u32 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8) | ((uint32_t)hdr[o + 2] << 16) | ((uint32_t)hdr[o + 3] << 24); };
+    auto u16 = [&](int o) { return (uint32_t)hdr[o] | ((uint32_t)hdr[o + 1] << 8); };
+    uint32_t W = u32(18), H = u32(22), bits = u16(28), comp = u32(30);
+    if (bits != 24 || comp != 0 || W == 0 || H == 0 || W > 32768 || H > 32768) {
+        std::fclose(f);
+        hs.warnings.push_back("unsupported BMP format, primitive left untextured: " + path);
+        return -1;
+    }
+    size_t padded = ((size_t)W * 3 + 3) & ~(size_t)3;
+    std::vector<uint8_t> row(padded), rgb((size_t)W * H * 3);
+    for (uint32_t i = 0; i < H; i++) {
+        size_t got = std::fread(row.data(), 1, padded, f);
+        if (got < padded) std::memset(row.data() + got, 0, padded - got);
+        for (uint32_t j = 0; j < W; j++) {
+            rgb[((size_t)i * W + j) * 3 + 0] = row[j * 3 + 2];
+            rgb[((size_t)i * W + j) * 3 + 1] = row[j * 3 + 1];
+            rgb[((size_t)i * W + j) * 3 + 2] = row[j * 3 + 0];
+        }
+    }
+    std::fclose(f);
+    hs.texture_data.push_back(std::move(rgb));
+    rt_texture t{};
+    t.width = (int32_t)W;
+    t.height = (int32_t)H;
+    t.rgb = nullptr;  // patched in finalize()
+    hs.textures.push_back(t);
+    return (int)hs.textures.size() - 1;
+}
+
+// ---- mesh files --------------------------------------------------------------------------
+// Vertex transform of CR/primitive.cpp:390-442: rotate about X, then Y, then Z, scale, translate.
+struct Xform {
+    double cx, sx, cy, sy, cz, sz;
+    V3 scale, O;
+    Xform(const V3& rot, const V3& s, const V3& o) : scale(s), O(o) {
+        cx = std::cos(rot.x), sx = std::sin(rot.x);
+        cy = std::cos(rot.y), sy = std::sin(rot.y);
+        cz = std::cos(rot.z), sz = std::sin(rot.z);
+    }
+    V3 apply(V3 v) const {
+        double y_new = cx * v.y - sx * v.z;
+        double z_new = sx * v.y + cx * v.z;
+        v.y = y_new;
+        v.z = z_new;
+        double x_new = cy * v.x + sy * v.z;
+        z_new = -sy * v.x + cy * v.z;
+        v.x = x_new;
+        v.z = z_new;
+        x_new = cz * v.x - sz * v.y;
+        y_new = sz * v.x + cz * v.y;
+        v.x = x_new;
+        v.y = y_new;
+        v.x *= scale.x;
+        v.y *= scale.y;
+        v.z *= scale.z;
+        v.x += O.x;
+        v.y += O.y;
+        v.z += O.z;
+        return v;
+    }
+};
+
+void add_vertex(HostMesh& m, std::vector<V3>& verts, const V3& v) {
+    m.vmin.x = std::min(m.vmin.x, v.x);
+    m.vmin.y = std::min(m.vmin.y, v.y);
+    m.vmin.z = std::min(m.vmin.z, v.z);
+    m.vmax.x = std::max(m.vmax.x, v.x);
+    m.vmax.y = std::max(m.vmax.y, v.y);
+    m.vmax.z = std::max(m.vmax.z, v.z);
+    verts.push_back(v);
+}
+
+bool add_face(HostMesh& m, const std::vector<V3>& verts, const int face[3]) {
+    for (int k = 0; k < 3; k++)
+        if (face[k] < 0 || (size_t)face[k] >= verts.size()) return false;  // the reference indexes out of bounds here
+    Tri t;
+    t.O1 = verts[face[0]];
+    t.O2 = verts[face[1]];
+    t.O3 = verts[face[2]];
+    t.face = (uint32_t)m.tris.size();
+    m.tris.push_back(t);
+    return true;
+}
+
+// OBJ subset of CR/primitive.cpp:395-468: "v x y z" and "f a b c" (1-based), everything else ignored.
+bool load_obj(const std::string& path, const Xform& xf, HostMesh& m, std::string& err) {
+    FILE* file = std::fopen(path.c_str(), "r");
+    if (!file) {
+        err = "cannot open mesh file " + path;
+        return false;
+    }
+    char line[256];
+    std::vector<V3> verts;
+    verts.reserve(50000);
+    m.tris.reserve(70000);
+    size_t bad = 0;
+    while (std::fgets(line, 256, file)) {
+        std::stringstream ss;
+        ss << line;
+        std::string type;
+        ss >> type;
+        if (type == "v") {
+            V3 v;
+            ss >> v.x >> v.y >> v.z;
+            add_vertex(m, verts, xf.apply(v));
+        } else if (type == "f") {
+            int face[3] = {0, 0, 0};
+            int vertex, i = 0;
+            while (ss >> vertex) {
+                if (i < 3) face[i] = vertex - 1;
+                i++;
+            }
+            if (!add_face(m, verts, face)) bad++;
+        }
+    }
+    std::fclose(file);
+    if (bad) {
+        err = "mesh file " + path + " has faces that index missing vertices";
+        return false;
+    }
+    return true;
+}
+
+// Packed mesh: "RTMESH1\0", u32 n_vertices, u32 n_faces, n_vertices*3 f64, n_faces*3 i32 (0-based).
+// Same vertices, faces and order as an OBJ would give; exists so large meshes ship as exact doubles.
+bool load_rtm(const std::string& path, const Xform& xf, HostMesh& m, std::string& err) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) {
+        err = "cannot open mesh file " + path;
+        return false;
+    }
+    char magic[8];
+    uint32_t nv = 0, nf = 0;
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "RTMESH1", 8) == 0 &&
+              std::fread(&nv, 4, 1, f) == 1 && std::fread(&nf, 4, 1, f) == 1 && nv < (1u << 28) && nf < (1u << 28);
+    std::vector<double> vb;
+    std::vector<int32_t> fb;
+    if (ok) {
+        vb.resize((size_t)nv * 3);
+        fb.resize((size_t)nf * 3);
+        ok = std::fread(vb.data(), 8, vb.size(), f) == vb.size() && std::fread(fb.data(), 4, fb.size(), f) == fb.size();
+    }
+    std::fclose(f);
+    if (!ok) {
+        err = "malformed packed mesh " + path;
+        return false;
+    }
+    std::vector<V3> verts;
+    verts.reserve(nv);
+    m.tris.reserve(nf);
+    for (uint32_t i = 0; i < nv; i++) add_vertex(m, verts, xf.apply(V3(vb[3 * i], vb[3 * i + 1], vb[3 * i + 2])));
+    for (uint32_t i = 0; i < nf; i++) {
+        int face[3] = {fb[3 * i], fb[3 * i + 1], fb[3 * i + 2]};
+        if (!add_face(m, verts, face)) {
+            err = "packed mesh " + path + " has faces that index missing vertices";
+            return false;
+        }
+    }
+    return true;
+}
+
+// ---- BVH (CR/primitive.cpp:552-616) ------------------------------------------------------
+struct Box {
+    V3 lo, hi;
+};
+struct Builder {
+    const std::vector<Tri>& tris;
+    std::vector<V3> centroid;
+    std::vector<rt_bvh_node>& nodes;
+    std::vector<rt_bvh_leaf>& leaves;
+    uint32_t preorder = 0, max_depth = 0;
+
+    Builder(const std::vector<Tri>& t, std::vector<rt_bvh_node>& n, std::vector<rt_bvh_leaf>& l) : tris(t), nodes(n), leaves(l) {
+        centroid.resize(t.size());
+        for (size_t i = 0; i < t.size(); i++) centroid[i] = (t[i].O1 + t[i].O2 + t[i].O3) / 3.0;
+    }
+
+    // returns the ref of the subtree built from `ids`; box receives its bounds
+    uint32_t build(std::vector<uint32_t>& ids, uint32_t depth, Box& box) {
+        max_depth = std::max(max_depth, depth);
+        if (ids.size() == 1) {
+            const Tri& t = tris[ids[0]];
+            box.lo = V3(std::min({t.O1.x, t.O2.x, t.O3.x}), std::min({t.O1.y, t.O2.y, t.O3.y}), std::min({t.O1.z, t.O2.z, t.O3.z}));
+            box.hi = V3(std::max({t.O1.x, t.O2.x, t.O3.x}), std::max({t.O1.y, t.O2.y, t.O3.y}), std::max({t.O1.z, t.O2.z, t.O3.z}));
+            rt_bvh_leaf lf{};
+            lf.O1 = pod(t.O1);
+            lf.O2 = pod(t.O2);
+            lf.O3 = pod(t.O3);
+            lf.skip = RT_REF_END;
+            lf.preorder = preorder++;
+            lf.face = t.face;
+            leaves.push_back(lf);
+            return RT_REF_LEAF | (uint32_t)(leaves.size() - 1);
+        }
+        uint32_t self = (uint32_t)nodes.size();
+        nodes.push_back(rt_bvh_node{});
+        nodes[self].preorder = preorder++;
+        int axis = (int)(depth % 3);
+        const std::vector<V3>& c = centroid;
+        std::sort(ids.begin(), ids.end(), [axis, &c](uint32_t a, uint32_t b) { return c[a][axis] < c[b][axis]; });
+        size_t mid = ids.size() / 2;
+        std::vector<uint32_t> l(ids.begin(), ids.begin() + mid), r(ids.begin() + mid, ids.end());
+        Box bl, br;
+        uint32_t lref = build(l, depth + 1, bl);
+        uint32_t rref = build(r, depth + 1, br);
+        box.lo = V3(std::min(bl.lo.x, br.lo.x), std::min(bl.lo.y, br.lo.y), std::min(bl.lo.z, br.lo.z));
+        box.hi = V3(std::max(bl.hi.x, br.hi.x), std::max(bl.hi.y, br.hi.y), std::max(bl.hi.z, br.hi.z));
+        rt_bvh_node& n = nodes[self];
+        n.bmin[0] = box.lo.x, n.bmin[1] = box.lo.y, n.bmin[2] = box.lo.z;
+        n.bmax[0] = box.hi.x, n.bmax[1] = box.hi.y, n.bmax[2] = box.hi.z;
+        n.left = lref;
+        n.right = rref;
+        n.skip = RT_REF_END;
+        return self;
+    }
+
+    void set_skip(uint32_t ref, uint32_t skip) {
+        if (ref == RT_REF_END) return;
+        if (ref & RT_REF_LEAF) {
+            leaves[ref & ~RT_REF_LEAF].skip = skip;
+            return;
+        }
+        nodes[ref].skip = skip;
+        set_skip(nodes[ref].left, nodes[ref].right);
+        set_skip(nodes[ref].right, skip);
+    }
+};
+
+int add_mesh(rt_host_scene& hs, const HostMesh& hm) {
+    rt_mesh m{};
+    m.node_base = (uint32_t)hs.nodes.size();
+    m.leaf_base = (uint32_t)hs.leaves.size();
+    m.root = RT_REF_END;
+    if (!hm.tris.empty()) {
+        Builder b(hm.tris, hs.nodes, hs.leaves);
+        std::vector<uint32_t> ids(hm.tris.size());
+        for (size_t i = 0; i < ids.size(); i++) ids[i] = (uint32_t)i;
+        Box box;
+        m.root = b.build(ids, 0, box);
+        b.set_skip(m.root, RT_REF_END);
+        m.depth = b.max_depth;
+        if (!(m.root & RT_REF_LEAF)) {
+            // the root box the renderer tests is the vertex bounding box (CR/Renderer_CUDA.cpp:234-235)
+            rt_bvh_node& n = hs.nodes[m.root];
+            n.bmin[0] = hm.vmin.x, n.bmin[1] = hm.vmin.y, n.bmin[2] = hm.vmin.z;
+            n.bmax[0] = hm.vmax.x, n.bmax[1] = hm.vmax.y, n.bmax[2] = hm.vmax.z;
+        }
+    }
+    m.node_count = (uint32_t)hs.nodes.size() - m.node_base;
+    m.leaf_count = (uint32_t)hs.leaves.size() - m.leaf_base;
+    hs.meshes.push_back(m);
+    return (int)hs.meshes.size() - 1;
+}
+
+// ---- key handlers ------------------------------------------------------------------------
+void material_input(rt_host_scene& hs, rt_material& m, const std::string& var, std::stringstream& fin) {
+    if (var == "color=") fin >> m.color.x >> m.color.y >> m.color.z;
+    if (var == "absor=") fin >> m.absor.x >> m.absor.y >> m.absor.z;
+    if (var == "refl=") fin >> m.refl;
+    if (var == "refr=") fin >> m.refr;
+    if (var == "diff=") fin >> m.diff;
+    if (var == "spec=") fin >> m.spec;
+    if (var == "drefl=") fin >> m.drefl;
+    if (var == "rindex=") fin >> m.rindex;
+    if (var == "texture=") {
+        std::string file;
+        fin >> file;
+        m.texture = load_texture(hs, file);
+    }
+}
+
+bool primitive_input(rt_host_scene& hs, HostPrim& p, const std::string& var, std::stringstream& fin, std::string& err) {
+    switch (p.type) {
+        case RT_PRIM_SPHERE:
+            if (var == "O=") read_v3(fin, p.O);
+            if (var == "R=") fin >> p.R;
+            if (var == "De=") read_v3(fin, p.De);
+            if (var == "Dc=") read_v3(fin, p.Dc);
+            break;
+        case RT_PRIM_PLANE:
+            if (var == "N=") read_v3(fin, p.N);
+            if (var == "R=") fin >> p.R;
+            if (var == "Dx=") read_v3(fin, p.Dx);
+            if (var == "Dy=") read_v3(fin, p.Dy);
+            break;
+        case RT_PRIM_SQUARE:
+            if (var == "O=") read_v3(fin, p.O);
+            if (var == "Dx=") read_v3(fin, p.Dx);
+            if (var == "Dy=") read_v3(fin, p.Dy);
+            break;
+        case RT_PRIM_CYLINDER:
+            if (var == "O1=") read_v3(fin, p.O1);
+            if (var == "O2=") read_v3(fin, p.O2);
+            if (var == "R=") fin >> p.R;
+            break;
+        case RT_PRIM_BEZIER:
+            if (var == "O1=") read_v3(fin, p.O1);
+            if (var == "O2=") {
+                read_v3(fin, p.O2);
+                p.N = unit(p.O2 - p.O1);
+                p.Nx = vertical(p.N);
+                p.Ny = cross(p.N, p.Nx);
+            }
+            if (var == "P=") {
+                p.degree++;
+                double newR = 0, newZ = 0;
+                fin >> newZ >> newR;
+                if (newR > p.R_c) p.R_c = newR;
+                p.bzR.push_back(newR);
+                p.bzZ.push_back(newZ);
+            }
+            break;
+        case RT_PRIM_TRIANGLE:
+            if (var == "O1=") read_v3(fin, p.O1);
+            if (var == "O2=") read_v3(fin, p.O2);
+            if (var == "O3=") {
+                read_v3(fin, p.O3);
+                p.N = unit(cross(p.O2 - p.O1, p.O3 - p.O1));
+            }
+            break;
+        case RT_PRIM_MESH:
+            if (var == "O=") read_v3(fin, p.O);
+            if (var == "rotation=") read_v3(fin, p.rotation);
+            if (var == "scale=") read_v3(fin, p.scale);
+            if (var == "file=") {
+                std::string file;
+                fin >> file;
+                std::string path = resolve(hs, file);
+                HostMesh hm;
+                Xform xf(p.rotation, p.scale, p.O);
+                bool packed = path.size() > 4 && path.compare(path.size() - 4, 4, ".rtm") == 0;
+                if (!(packed ? load_rtm(path, xf, hm, err) : load_obj(path, xf, hm, err))) return false;
+                p.mesh = add_mesh(hs, hm);
+            }
+            break;
+        default:
+            break;
+    }
+    material_input(hs, p.mat, var, fin);
+    return true;
+}
+
+void light_input(HostLight& l, const std::string& var, std::stringstream& fin) {
+    if (var == "O=") read_v3(fin, l.O);
+    if (l.type == RT_LIGHT_SQUARE) {
+        if (var == "Dx=") read_v3(fin, l.Dx);
+        if (var == "Dy=") read_v3(fin, l.Dy);
+    }
+    if (l.type == RT_LIGHT_SPHERE && var == "R=") fin >> l.R;
+    if (var == "color=") read_v3(fin, l.color);
+}
+
+struct HostCamera {
+    V3 O{0, 0, 0}, N{0, 1, 0}, Dx, Dy;
+    double lens_W = 0.88, lens_H = 0.88;
+    int W = 420, H = 420;
+    double shade_quality = 4, drefl_quality = 4;
+    void input(const std::string& var, std::stringstream& fin) {
+        if (var == "O=") read_v3(fin, O);
+        if (var == "N=") {
+            read_v3(fin, N);
+            N = unit(N);
+        }
+        if (var == "lens_W=") fin >> lens_W;
+        if (var == "lens_H=") fin >> lens_H;
+        if (var == "image_W=") fin >> W;
+        if (var == "image_H=") fin >> H;
+        if (var == "shade_quality=") fin >> shade_quality;
+        if (var == "drefl_quality=") fin >> drefl_quality;
+    }
+    void initialize() {
+        N = unit(N);
+        Dx = vertical(N);
+        Dy = cross(Dx, N);
+        Dx = Dx * lens_W / 2;
+        Dy = Dy * lens_H / 2;
+    }
+};
+
+rt_primitive to_pod(const HostPrim& p, std::string& err) {
+    rt_primitive q;
+    std::memset(&q, 0, sizeof(q));
+    q.type = p.type;
+    q.is_light = p.is_light ? 1 : 0;
+    q.material = p.mat;
+    switch (p.type) {
+        case RT_PRIM_SPHERE:
+            q.u.sphere.O = pod(p.O), q.u.sphere.De = pod(p.De), q.u.sphere.Dc = pod(p.Dc), q.u.sphere.R = p.R;
+            break;
+        case RT_PRIM_PLANE:
+            q.u.plane.N = pod(p.N), q.u.plane.Dx = pod(p.Dx), q.u.plane.Dy = pod(p.Dy), q.u.plane.R = p.R;
+            break;
+        case RT_PRIM_SQUARE:
+            q.u.square.O = pod(p.O), q.u.square.Dx = pod(p.Dx), q.u.square.Dy = pod(p.Dy);
+            break;
+        case RT_PRIM_CYLINDER:
+            q.u.cylinder.O1 = pod(p.O1), q.u.cylinder.O2 = pod(p.O2), q.u.cylinder.R = p.R;
+            break;
+        case RT_PRIM_BEZIER:
+            q.u.bezier.O1 = pod(p.O1), q.u.bezier.O2 = pod(p.O2), q.u.bezier.N = pod(p.N);
+            q.u.bezier.Nx = pod(p.Nx), q.u.bezier.Ny = pod(p.Ny), q.u.bezier.R_c = p.R_c;
+            q.u.bezier.degree = p.degree;
+            if (p.bzR.size() > RT_BEZIER_MAX_CTRL) {
+                err = "bezier primitive has more than 10 control points";
+                break;
+            }
+            for (size_t i = 0; i < p.bzR.size(); i++) q.u.bezier.R[i] = p.bzR[i], q.u.bezier.Z[i] = p.bzZ[i];
+            break;
+        case RT_PRIM_TRIANGLE:
+            q.u.triangle.O1 = pod(p.O1), q.u.triangle.O2 = pod(p.O2), q.u.triangle.O3 = pod(p.O3), q.u.triangle.N = pod(p.N);
+            break;
+        case RT_PRIM_MESH:
+            q.u.mesh.mesh = p.mesh;
+            break;
+    }
+    return q;
+}
+
+void finalize(rt_host_scene& hs) {
+    for (size_t i = 0; i < hs.textures.size(); i++) hs.textures[i].rgb = hs.texture_data[i].data();
+    rt_scene_desc& d = hs.desc;
+    d.n_lights = (int32_t)hs.lights.size();
+    d.n_primitives = (int32_t)hs.prims.size();
+    d.n_textures = (int32_t)hs.textures.size();
+    d.n_meshes = (int32_t)hs.meshes.size();
+    d.n_nodes = (uint32_t)hs.nodes.size();
+    d.n_leaves = (uint32_t)hs.leaves.size();
+    d.lights = hs.lights.data();
+    d.primitives = hs.prims.data();
+    d.textures = hs.textures.data();
+    d.meshes = hs.meshes.data();
+    d.nodes = hs.nodes.data();
+    d.leaves = hs.leaves.data();
+}
+
+}  // namespace
+
+extern "C" int rt_host_scene_load(const char* scene_path, const char* asset_dir, rt_host_scene** out) {
+    if (!scene_path || !out) return rt_fail(RT_ERR_INVALID, "rt_host_scene_load: null argument");
+    *out = nullptr;
+    std::ifstream fin(scene_path);
+    if (!fin) return rt_fail(RT_ERR_IO, std::string("cannot open scene file ") + scene_path);
+    std::unique_ptr<rt_host_scene> hs(new rt_host_scene);
+    if (asset_dir) hs->asset_dir = asset_dir;
+
+    V3 bg_top, bg_bottom;
+    HostCamera cam;
+    std::vector<HostPrim> prims;    // file order
+    std::vector<HostLight> lights;  // file order
+    std::string err;
+
+    // Token loop of CR/raytracer.cpp:203-271.  A '#' skips one token only, so a comment that
+    // contains a block keyword opens that block; unknown primitive / light types still
+    // consume their block.
+    std::string obj;
+    while (fin >> obj) {
+        if (obj[0] == '#') continue;
+        HostPrim* new_primitive = nullptr;
+        HostLight* new_light = nullptr;
+        if (obj == "primitive") {
+            std::string type;
+            fin >> type;
+            int t = -1;
+            if (type == "sphere") t = RT_PRIM_SPHERE;
+            if (type == "plane") t = RT_PRIM_PLANE;
+            if (type == "square") t = RT_PRIM_SQUARE;
+            if (type == "cylinder") t = RT_PRIM_CYLINDER;
+            if (type == "bezier") t = RT_PRIM_BEZIER;
+            if (type == "triangle") t = RT_PRIM_TRIANGLE;
+            if (type == "mesh") t = RT_PRIM_MESH;
+            if (t >= 0) {
+                prims.emplace_back();
+                prims.back().type = t;
+                new_primitive = &prims.back();
+            }
+        } else if (obj == "light") {
+            std::string type;
+            fin >> type;
+            int t = -1;
+            if (type == "point") t = RT_LIGHT_POINT;
+            if (type == "square") t = RT_LIGHT_SQUARE;
+            if (type == "sphere") t = RT_LIGHT_SPHERE;
+            if (t >= 0) {
+                lights.emplace_back();
+                lights.back().type = t;
+                new_light = &lights.back();
+            }
+        } else if (obj != "background" && obj != "camera")
+            continue;
+
+        fin.ignore(1024, '\n');
+        std::string order;
+        while (std::getline(fin, order, '\n')) {
+            std::stringstream fin2(order);
+            std::string var;
+            fin2 >> var;
+            if (!var.empty() && var[0] == '#') continue;
+            if (var == "end") break;
+            if (obj == "background") {
+                if (var == "color=") {
+                    read_v3(fin2, bg_top);
+                    bg_bottom = bg_top;
+                } else if (var == "top=") {
+                    read_v3(fin2, bg_top);
+                    bg_bottom = V3(1.0, 1.0, 1.0);
+                } else if (var == "bottom=") {
+                    read_v3(fin2, bg_bottom);
+                }
+            }
+            if (obj == "primitive" && new_primitive) {
+                if (!primitive_input(*hs, *new_primitive, var, fin2, err)) return rt_fail(RT_ERR_IO, err);
+            }
+            if (obj == "light" && new_light) light_input(*new_light, var, fin2);
+            if (obj == "camera") cam.input(var, fin2);
+        }
+    }
+    cam.initialize();
+
+    // List order (CR/raytracer.cpp:180-193,221-224,232-235): primitives and lights are
+    // prepended, so both lists run in reverse file order; then one primitive per area light
+    // is prepended while walking the light list, which leaves them in file order up front.
+    std::vector<HostPrim> plist;
+    std::vector<int> light_prim_of(lights.size(), -1);
+    for (size_t i = 0; i < lights.size(); i++) {
+        const HostLight& l = lights[i];
+        if (l.type == RT_LIGHT_POINT) continue;
+        HostPrim p;
+        p.is_light = true;
+        p.mat.color = pod(l.color);
+        if (l.type == RT_LIGHT_SQUARE) {
+            p.type = RT_PRIM_SQUARE;
+            p.O = l.O, p.Dx = l.Dx, p.Dy = l.Dy;
+        } else {
+            p.type = RT_PRIM_SPHERE;
+            p.O = l.O, p.R = l.R;
+        }
+        light_prim_of[i] = (int)plist.size();
+        plist.push_back(p);
+    }
+    for (size_t i = prims.size(); i-- > 0;) plist.push_back(prims[i]);
+    for (const HostPrim& p : plist) {
+        hs->prims.push_back(to_pod(p, err));
+        if (!err.empty()) return rt_fail(RT_ERR_LIMIT, err);
+    }
+    for (size_t i = lights.size(); i-- > 0;) {
+        const HostLight& l = lights[i];
+        rt_light q;
+        std::memset(&q, 0, sizeof(q));
+        q.type = l.type;
+        q.light_primitive = light_prim_of[i];
+        q.color = pod(l.color), q.O = pod(l.O), q.Dx = pod(l.Dx), q.Dy = pod(l.Dy), q.R = l.R;
+        hs->lights.push_back(q);
+    }
+
+    rt_scene_desc& d = hs->desc;
+    d.background_top = pod(bg_top);
+    d.background_bottom = pod(bg_bottom);
+    d.camera.O = pod(cam.O), d.camera.N = pod(cam.N), d.camera.Dx = pod(cam.Dx), d.camera.Dy = pod(cam.Dy);
+    d.camera.W = cam.W, d.camera.H = cam.H;
+    d.camera.shade_quality = cam.shade_quality, d.camera.drefl_quality = cam.drefl_quality;
+    d.camera.lens_W = cam.lens_W, d.camera.lens_H = cam.lens_H;
+    finalize(*hs);
+    *out = hs.release();
+    return RT_OK;
+}
+
+extern "C" int rt_host_scene_set_viewport(rt_host_scene* hs, int width, int height) {
+    if (!hs || width <= 0 || height <= 0) return rt_fail(RT_ERR_INVALID, "rt_host_scene_set_viewport: bad argument");
+    hs->desc.camera.W = width;
+    hs->desc.camera.H = height;
+    return RT_OK;
+}
+
+extern "C" const rt_scene_desc* rt_host_scene_desc(const rt_host_scene* hs) { return hs ? &hs->desc : nullptr; }
+
+extern "C" int rt_host_scene_warning_count(const rt_host_scene* hs) { return hs ? (int)hs->warnings.size() : 0; }
+extern "C" const char* rt_host_scene_warning(const rt_host_scene* hs, int i) {
+    return (hs && i >= 0 && (size_t)i < hs->warnings.size()) ? hs->warnings[i].c_str() : nullptr;
+}
+
+extern "C" void rt_host_scene_free(rt_host_scene* hs) { delete hs; }
+
+extern "C" int rt_bmp_save_rgba(const char* path, const uint8_t* rgba, int width, int height) {
+    if (!path || !rgba || width <= 0 || height <= 0) return rt_fail(RT_ERR_INVALID, "rt_bmp_save_rgba: bad argument");
+    uint32_t data = (uint32_t)width * (uint32_t)height * 3u;
+    unsigned char hdr[54];
+    std::memset(hdr, 0, sizeof(hdr));
+    auto p32 = [&](int o, uint32_t v) { hdr[o] = v & 255, hdr[o + 1] = (v >> 8) & 255, hdr[o + 2] = (v >> 16) & 255, hdr[o + 3] = (v >> 24) & 255; };
+    hdr[0] = 'B', hdr[1] = 'M';
+    p32(2, 54u + data);
+    p32(10, 54u);
+    p32(14, 40u);
+    p32(18, (uint32_t)width);
+    p32(22, (uint32_t)height);
+    hdr[26] = 1;
+    hdr[28] = 24;
+    p32(34, data);
+    std::vector<uint8_t> bgr((size_t)data);
+    for (size_t i = 0; i < (size_t)width * height; i++) {
+        bgr[3 * i + 0] = rgba[4 * i + 2];
+        bgr[3 * i + 1] = rgba[4 * i + 1];
+        bgr[3 * i + 2] = rgba[4 * i + 0];
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return rt_fail(RT_ERR_IO, std::string("cannot open for writing: ") + path);
+    bool ok = std::fwrite(hdr, 1, 54, f) == 54 && std::fwrite(bgr.data(), 1, bgr.size(), f) == bgr.size();
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : rt_fail(RT_ERR_IO, std::string("short write: ") + path);
+}
