@@ -26,13 +26,13 @@ RT_F_SHADOW_SELF_SKIP = 0x008
 RT_F_SQUARE_UV_NO_ORIGIN = 0x010
 RT_F_TEX_U8_TAPS = 0x020
 RT_F_PIXEL_MAP_TRUNC = 0x040
-RT_F_MESH_SHADOW_RAW = 0x080
+RT_F_MESH_RAW_DIR = 0x080
 RT_F_BEZIER_STACKED = 0x100
 RT_F_STRICT_TRAVERSAL = 0x200
 RT_MODE_CPU_REF = 0
 RT_MODE_GPU_REF = (
     RT_F_NORMALIZE_PRIMARY | RT_F_SKY_Y | RT_F_TIE_LATER_WINS | RT_F_SHADOW_SELF_SKIP | RT_F_SQUARE_UV_NO_ORIGIN
-    | RT_F_TEX_U8_TAPS | RT_F_PIXEL_MAP_TRUNC | RT_F_MESH_SHADOW_RAW | RT_F_BEZIER_STACKED
+    | RT_F_TEX_U8_TAPS | RT_F_PIXEL_MAP_TRUNC | RT_F_MESH_RAW_DIR | RT_F_BEZIER_STACKED
 )
 
 

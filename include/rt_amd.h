@@ -51,7 +51,7 @@ enum { RT_LIGHT_POINT = 0, RT_LIGHT_SQUARE = 1, RT_LIGHT_SPHERE = 2 };
 
 /* ---- semantics flags ---------------------------------------------------------------------
  * The reference has two renderers that disagree in small ways: the CPU path
- * (CR/raytracer.cpp, CR/primitive.cpp, CR/Light.cpp) and the CUDA path (CR/*.cu).  Each
+ * (CR/raytracer.cpp, CR/primitive.cpp, CR/Light.cpp) and the CUDA path (the .cu files).  Each
  * disagreement is one bit; a cleared bit selects the CPU path's behaviour.               */
 #define RT_F_NORMALIZE_PRIMARY 0x001u /* primary direction normalised before tracing (CR/RayTracer.cu:60,65,78) vs raw Camera::Emit (CR/camera.cpp:57-59) */
 #define RT_F_SKY_Y 0x002u             /* sky gradient on dir.y (CR/Scene.cu:51) vs dir.z (CR/raytracer.cpp:169)                      */
@@ -60,14 +60,14 @@ enum { RT_LIGHT_POINT = 0, RT_LIGHT_SQUARE = 1, RT_LIGHT_SPHERE = 2 };
 #define RT_F_SQUARE_UV_NO_ORIGIN 0x010u /* square UV from C.Dx (CR/Primitive.cu:46-47) vs (C-O).Dx (CR/primitive.cpp:230-231)           */
 #define RT_F_TEX_U8_TAPS 0x020u       /* each bilinear tap truncated to 8 bits before summing (helper_math.h:1842-1844) vs double taps (CR/bmp.cpp:146-149) */
 #define RT_F_PIXEL_MAP_TRUNC 0x040u   /* pixel->camera map int((double)x/tex_w*cam_w) (CR/RayTracer.cu:55-56) vs exact floor(x*cam_w/tex_w) */
-#define RT_F_MESH_SHADOW_RAW 0x080u   /* mesh shadow t left in units of |L-C| (CR/Collision_Mesh.cu:19-63 does not normalise) vs world units */
+#define RT_F_MESH_RAW_DIR 0x080u      /* mesh / triangle intersectors take the direction as given, so t is in units of |d| (CR/Collision_Mesh.cu:19-63, CR/Collision.cu:110-149; matters for shadow rays d = L-C and fuzzy reflections) vs normalised first like every other intersector */
 #define RT_F_BEZIER_STACKED 0x100u    /* Bezier = stack of cylinders incl. the `closest` bookkeeping of CR/Collision_Bezier.cu:200-240 vs Newton on the true surface of revolution */
 #define RT_F_STRICT_TRAVERSAL 0x200u  /* BVH walked exactly as CR/Collision_Mesh.cu:65-80: no t culling, no any-hit early out (results are identical either way; visit counts are not) */
 
 #define RT_MODE_CPU_REF 0u
 #define RT_MODE_GPU_REF                                                                          \
     (RT_F_NORMALIZE_PRIMARY | RT_F_SKY_Y | RT_F_TIE_LATER_WINS | RT_F_SHADOW_SELF_SKIP |           \
-     RT_F_SQUARE_UV_NO_ORIGIN | RT_F_TEX_U8_TAPS | RT_F_PIXEL_MAP_TRUNC | RT_F_MESH_SHADOW_RAW |   \
+     RT_F_SQUARE_UV_NO_ORIGIN | RT_F_TEX_U8_TAPS | RT_F_PIXEL_MAP_TRUNC | RT_F_MESH_RAW_DIR |   \
      RT_F_BEZIER_STACKED)
 
 /* ---- host-side scene description (flat POD; replaces the pointer graph of CR/Scene.cuh:22-32) */
