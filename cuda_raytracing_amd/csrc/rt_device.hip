@@ -1,0 +1,810 @@
+// Render kernels for gfx950 and the device half of the C ABI (include/rt_amd.h).
+//
+// Execution model (wave64, no LDS, no MFMA - this is a pointer walk, not a contraction):
+//   * a persistent grid: every wave pops tasks from one atomic counter until it runs dry;
+//   * a task = the samples of a small group of pixels, one (pixel, sample) per lane, so the 64
+//     lanes of a wave trace 64 paths at once and the image is resolved in-wave: per-sample
+//     colours are summed in sample order through lane reads (the reference adds them in that
+//     order inside one thread, CR/RayTracer.cu:74-84, and double addition is not associative);
+//   * the recursion of CR/Scene.cu:23-58 becomes a loop over an explicit frame stack (<= 10
+//     frames per lane, in scratch) that visits reflect / refract children in the reference's
+//     order, so each path consumes its random draws in the same sequence;
+//   * shading is wave-cooperative: the shadow rays of all lanes that need shading (one per
+//     point light, 16*shade_quality per area light, CR/Shade.cu:23-113) are dealt out over all
+//     64 lanes, 64 at a time.  Rays of one shaded point fly to the same small lamp, so
+//     neighbouring lanes walk the same BVH nodes.  Visible-sample counts are integers, so the
+//     sum does not depend on which lane traced which ray.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_amd.h"
+#include "rt_internal.h"
+#include "rt_trace.hpp"
+
+static_assert(sizeof(rt_bvh_node) == 64 && sizeof(rt_bvh_leaf) == 96, "BVH record sizes are part of the ABI");
+static_assert(sizeof(rt_primitive) == 408 && sizeof(rt_light) == 112 && sizeof(rt_scene_desc) == 256 && sizeof(rt_settings) == 40 &&
+                  sizeof(rt_stats) == 80,
+              "record sizes are part of the ABI (the Python binding mirrors them)");
+
+struct Tile {
+    int32_t x0, y0, w, h;
+};
+
+struct RenderParams {
+    DevScene sc;
+    int32_t tex_w, tex_h, spp, dof;
+    double focal, aperture;
+    uint32_t k0, k1, flags;
+    int32_t n_tiles, ppt;  // ppt = pixels per task
+    uint32_t n_tasks;
+    const Tile* tiles;
+    const uint32_t* tile_prefix;  // n_tiles + 1 entries: first task of each tile
+    uint32_t* queue;
+    uint8_t* out;  // tex_w * tex_h * 4, row 0 = bottom
+    unsigned long long* counters;
+};
+
+enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT };
+
+// ---- camera: CR/RayTracer.cu:52-61, CR/camera.cpp:57-59 -------------------------------------------
+DEV d3 emit(const DevScene& sc, double x, double y) {
+    return sc.camN + sc.camDy * (2 * y / sc.cam_h - 1) + sc.camDx * (2 * x / sc.cam_w - 1);
+}
+DEV void map_pixel(const RenderParams& P, int sx, int sy, int& x, int& y) {
+    if (P.flags & RT_F_PIXEL_MAP_TRUNC) {
+        x = (int)((double)sx / P.tex_w * P.sc.cam_w);
+        y = (int)((double)sy / P.tex_h * P.sc.cam_h);
+    } else {
+        x = (int)(((long long)sx * P.sc.cam_w) / P.tex_w);
+        y = (int)(((long long)sy * P.sc.cam_h) / P.tex_h);
+    }
+}
+DEV d3 clamp1(d3 c) {  // Color::Confine, CR/color.cpp:53-57 / CR/Scene.cu:54-56
+    if (c.x > 1) c.x = 1;
+    if (c.y > 1) c.y = 1;
+    if (c.z > 1) c.z = 1;
+    return c;
+}
+DEV uint32_t to_u8(double c) {
+    double v = c * 255;
+    if (!(v >= 0)) return 0;
+    if (v > 255) return 255;
+    return (uint32_t)(int)v;
+}
+
+// ---- CalnDiffusion for every lane that needs it, shadow rays dealt over the wave ---------------
+// CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
+template <bool STRICT>
+DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need, const Hit& h, uint32_t& draw, uint32_t pixel,
+                      uint32_t smp, Counters& ctr) {
+    const DevScene& sc = P.sc;
+    const int lane = lane_id();
+    const int nshade = __popcll(mask);
+    const int my_rank = need ? rank_in(mask) : nshade + rank_in(~mask);
+    // lane r learns which lane owns shading slot r
+    const int owner_tbl = __builtin_amdgcn_ds_permute(my_rank << 2, lane);
+
+    d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
+    if (need) {
+        const rt_material& m = sc.prims[h.prim].material;
+        color = D3(m.color);
+        if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, h, ctr));
+        ctr.shaded++;
+    }
+    uint32_t off = 0;
+    for (int l = 0; l < sc.n_lights; l++) {
+        const rt_light& L = sc.lights[l];
+        const bool point = L.type == RT_LIGHT_POINT;
+        const int n_l = point ? 1 : sc.shade_n;
+        const int total = nshade * n_l;
+        int cnt = 0;
+        for (int base = 0; base < total; base += 64) {
+            const int item = base + lane;
+            const bool act = item < total;
+            const int r = act ? item / n_l : 0;
+            const int si = item - r * n_l;
+            const int owner = __shfl(owner_tbl, r, 64);
+            const d3 C = shfl_d3(h.C, owner);
+            const int crashed = __shfl(h.prim, owner, 64);
+            const uint32_t opix = __shfl(pixel, owner, 64), osmp = __shfl(smp, owner, 64), odraw = __shfl(draw, owner, 64);
+            bool clear = false;
+            if (act) {
+                d3 target = D3(L.O);
+                if (!point) {
+                    float fa, fb;
+                    frand_pair(P.k0, P.k1, opix, osmp, odraw + off + 2u * (uint32_t)si, fa, fb);
+                    target = light_sample(L, fa, fb);
+                }
+                ctr.rays_shadow++;
+                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ctr);
+            }
+            const unsigned long long cm = __ballot(clear);
+            if (need) {
+                int lo = my_rank * n_l - base, hi = lo + n_l;
+                if (lo < 0) lo = 0;
+                if (hi > 64) hi = 64;
+                if (hi > lo) {
+                    unsigned long long bits = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                    cnt += __popcll(cm & bits);
+                }
+            }
+        }
+        if (need) {
+            double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
+            if (!(shade < RT_EPS)) {
+                const rt_material& m = sc.prims[h.prim].material;
+                d3 R = unit(D3(L.O) - h.C);
+                double dt = dot(R, h.N);
+                if (dt > RT_EPS) {
+                    if (m.diff > RT_EPS) {
+                        double diff = m.diff * dt * shade;
+                        ret = ret + mulv(color, D3(L.color)) * diff;
+                    }
+                    if (m.spec > RT_EPS) {
+                        double spec = m.spec * pow(dt, (double)RT_SPEC_POWER) * shade;
+                        ret = ret + mulv(color, D3(L.color)) * spec;
+                    }
+                }
+            }
+        }
+        if (!point) off += 2u * (uint32_t)n_l;
+    }
+    if (need) draw += off;
+    return ret;
+}
+
+// ---- one path per lane: CR/Scene.cu:23-58 + CR/Scene_Material.cu:68-118 as a loop ----------------
+enum { ST_REFL = 1, ST_REFR = 2, ST_PENDING_REFR = 4, ST_FRONT = 8 };
+
+template <bool STRICT>
+DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t smp, d3 o, d3 d, uint32_t draw, Counters& ctr) {
+    const DevScene& sc = P.sc;
+    // frame k = the hit at depth k+1 that is waiting for a child ray to return
+    double f_acc[RT_MAX_DEPTH][3], f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3], f_dist[RT_MAX_DEPTH];
+    int32_t f_prim[RT_MAX_DEPTH];
+    uint32_t f_stage[RT_MAX_DEPTH];
+    int sp = 0;
+    bool tracing = active;
+    d3 final_c = D3(0, 0, 0);
+    uint32_t no_log = 0;
+
+    while (__ballot(tracing) != 0ull) {
+        Hit h;
+        h.prim = -1, h.leaf = -1, h.dist = RT_BIG_DIST, h.front = false, h.N = D3(0, 0, 0), h.C = D3(0, 0, 0);
+        bool surface = false;
+        d3 result = D3(0, 0, 0);
+        if (tracing && sp + 1 <= RT_MAX_DEPTH) {
+            if (sp > 0) ctr.rays_secondary++;
+            h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log);
+            if (h.prim < 0) {
+                d3 c = unit(d);
+                double t = 0.5 * (((P.flags & RT_F_SKY_Y) ? c.y : c.z) + 1.0);
+                result = clamp1(sc.bg_bottom * (1.0 - t) + sc.bg_top * t);
+            } else if (sc.prims[h.prim].is_light) {
+                result = clamp1(D3(sc.prims[h.prim].material.color));
+            } else {
+                surface = true;
+            }
+        }
+        bool need_shade = false;
+        if (surface) {
+            const rt_material& m = sc.prims[h.prim].material;
+            need_shade = m.diff > RT_EPS || m.spec > RT_EPS;
+        }
+        d3 local = D3(0, 0, 0);
+        const unsigned long long mask = __ballot(need_shade);
+        if (mask != 0ull) local = diffusion_coop<STRICT>(P, mask, need_shade, h, draw, pixel, smp, ctr);
+
+        if (tracing) {
+            bool have_result = !surface;
+            if (surface) {
+                const rt_material& m = sc.prims[h.prim].material;
+                d3 acc = D3(0, 0, 0);
+                if (need_shade) acc = acc + local;
+                const bool has_refl = m.refl > RT_EPS, has_refr = m.refr > RT_EPS;
+                if (has_refl || has_refr) {
+                    const int k = sp;
+                    f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
+                    f_C[k][0] = h.C.x, f_C[k][1] = h.C.y, f_C[k][2] = h.C.z;
+                    f_N[k][0] = h.N.x, f_N[k][1] = h.N.y, f_N[k][2] = h.N.z;
+                    f_V[k][0] = d.x, f_V[k][1] = d.y, f_V[k][2] = d.z;
+                    f_dist[k] = h.dist;
+                    f_prim[k] = h.prim;
+                    uint32_t st = h.front ? ST_FRONT : 0;
+                    d3 nd;
+                    if (has_refl) {  // CalnReflection, CR/Scene_Material.cu:68-99
+                        st |= ST_REFL | (has_refr ? ST_PENDING_REFR : 0);
+                        d3 rv = reflect(d, h.N);
+                        const int dep = sp + 1;
+                        if (m.drefl < RT_EPS || dep > RT_MAX_DREFL_DEP) {
+                            nd = rv;
+                        } else {
+                            d3 bx = vertical(rv);
+                            d3 by = unit(cross(rv, bx));
+                            bx = bx * m.drefl;
+                            by = by * m.drefl;
+                            float fx, fy;  // GetBlur, CR/Scene_Material.cu:19-27
+                            frand_pair(P.k0, P.k1, pixel, smp, draw, fx, fy);
+                            draw += 2;
+                            double x = fx, y = fy;
+                            double bxk = x * cos(y), byk = x * sin(y);
+                            nd = rv + bx * bxk + by * byk;
+                        }
+                    } else {  // CalnRefraction, CR/Scene_Material.cu:101-118
+                        st |= ST_REFR;
+                        double n = m.rindex;
+                        if (h.front) n = 1.0 / n;
+                        nd = refract(d, h.N, n);
+                    }
+                    f_stage[k] = st;
+                    sp++;
+                    o = h.C;
+                    d = nd;
+                } else {
+                    result = clamp1(acc);
+                    have_result = true;
+                }
+            }
+            // hand `result` to the frames that wait for it
+            while (have_result) {
+                if (sp == 0) {
+                    final_c = result;
+                    tracing = false;
+                    break;
+                }
+                const int k = sp - 1;
+                const rt_material& m = sc.prims[f_prim[k]].material;
+                const uint32_t st = f_stage[k];
+                d3 contrib;
+                if (st & ST_REFL) {
+                    contrib = mulv(result, D3(m.color)) * m.refl;
+                } else if (st & ST_FRONT) {
+                    contrib = result * m.refr;
+                } else {
+                    d3 ab = D3(m.absor) * -f_dist[k];
+                    d3 tr = D3(exp(ab.x), exp(ab.y), exp(ab.z));
+                    contrib = mulv(result, tr) * m.refr;
+                }
+                d3 acc = D3(f_acc[k][0], f_acc[k][1], f_acc[k][2]) + contrib;
+                if ((st & ST_REFL) && (st & ST_PENDING_REFR)) {
+                    f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
+                    f_stage[k] = (st & ST_FRONT) | ST_REFR;
+                    double n = m.rindex;
+                    if (st & ST_FRONT) n = 1.0 / n;
+                    d3 V = D3(f_V[k][0], f_V[k][1], f_V[k][2]), N = D3(f_N[k][0], f_N[k][1], f_N[k][2]);
+                    o = D3(f_C[k][0], f_C[k][1], f_C[k][2]);
+                    d = refract(V, N, n);
+                    have_result = false;  // the refraction child is traced next (depth k+2 = sp+1)
+                } else {
+                    result = clamp1(acc);
+                    sp--;
+                }
+            }
+        }
+    }
+    return final_c;
+}
+
+// ---- the render kernel: CR/RayTracer.cu:40-94 --------------------------------------------------
+template <bool STRICT>
+__global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
+    const int lane = lane_id();
+    const DevScene& sc = P.sc;
+    Counters ctr;
+    ctr.rays_secondary = ctr.rays_shadow = ctr.nodes = ctr.tris = ctr.shaded = ctr.texfetch = 0;
+    const int spp = P.spp;
+    const int group = spp <= 64 ? spp : 64;        // lanes per pixel within one pass
+    const int passes = spp <= 64 ? 1 : (spp + 63) / 64;
+    const int slot = lane / group, sub = lane - slot * group;
+
+    for (;;) {
+        uint32_t task = 0;
+        if (lane == 0) task = atomicAdd(P.queue, 1u);
+        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
+        if (task >= P.n_tasks) break;
+        int lo = 0, hi = P.n_tiles;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (P.tile_prefix[mid] <= task) lo = mid;
+            else hi = mid;
+        }
+        const Tile tile = P.tiles[lo];
+        const uint32_t local = task - P.tile_prefix[lo];
+        // pixels of a tile are numbered in 8x8 blocks, row-major inside a block
+        const int nbx = (tile.w + 7) >> 3;
+        const uint32_t q = local * (uint32_t)P.ppt + (uint32_t)slot;
+        const int blk = (int)(q >> 6), inb = (int)(q & 63u);
+        const int px = tile.x0 + (blk % nbx) * 8 + (inb & 7), py = tile.y0 + (blk / nbx) * 8 + (inb >> 3);
+        const bool valid = slot < P.ppt && px < tile.x0 + tile.w && py < tile.y0 + tile.h;
+        const uint32_t pixel = (uint32_t)py * (uint32_t)P.tex_w + (uint32_t)px;
+
+        int x = 0, y = 0;
+        d3 dc = D3(0, 0, 1), focal = D3(0, 0, 0);
+        if (valid) {
+            map_pixel(P, px, py, x, y);
+            dc = unit(emit(sc, x, y));
+            focal = sc.camO + dc * P.focal;
+        }
+        d3 acc = D3(0, 0, 0);
+        for (int pass = 0; pass < passes; pass++) {
+            const int s = pass * 64 + sub;
+            const bool active = valid && s < spp;
+            d3 o = sc.camO, d = dc;
+            uint32_t draw = 0;
+            if (active) {
+                if (spp == 1) {
+                    if (!(P.flags & RT_F_NORMALIZE_PRIMARY)) d = emit(sc, x, y);
+                } else {
+                    float fu, fv;
+                    frand_pair(P.k0, P.k1, pixel, (uint32_t)s, 0u, fu, fv);
+                    draw = 2;
+                    double u = x + (2.0f * fu - 1.0f);
+                    double v = y + (2.0f * fv - 1.0f);
+                    d = emit(sc, u, v);
+                    if (P.flags & RT_F_NORMALIZE_PRIMARY) d = unit(d);
+                }
+                if (P.dof) {  // modifyRayForDepthOfField, CR/RayTracer.cu:31-38
+                    float fa, fb;
+                    frand_pair(P.k0, P.k1, pixel, (uint32_t)s, draw, fa, fb);
+                    draw += 2;
+                    double rx = (fa - 0.5) * P.aperture / 10.0;
+                    double ry = (fb - 0.5) * P.aperture / 10.0;
+                    o = o + (sc.camDx * rx + sc.camDy * ry);
+                    d = unit(focal - o);
+                }
+            }
+            d3 col = trace_paths<STRICT>(P, active, pixel, (uint32_t)s, o, d, draw, ctr);
+            // add this pass's samples in sample order
+            const int n_here = (spp - pass * 64) < group ? (spp - pass * 64) : group;
+            const int first = slot * group;
+            for (int j = 0; j < n_here; j++) acc = acc + shfl_d3(col, (first + j) & 63);
+        }
+        if (spp > 1) acc = acc / (double)spp;
+        if (valid && sub == 0) {
+            uint32_t rgba = to_u8(acc.x) | (to_u8(acc.y) << 8) | (to_u8(acc.z) << 16) | 0xFF000000u;
+            *reinterpret_cast<uint32_t*>(P.out + (size_t)pixel * 4) = rgba;
+        }
+    }
+    unsigned long long v[CTR_COUNT] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch};
+#pragma unroll
+    for (int i = 0; i < CTR_COUNT; i++) {
+        unsigned long long s = wave_sum_u64(v[i]);
+        if (lane == 0 && s) atomicAdd(&P.counters[i], s);
+    }
+}
+
+// ---- debug kernel: primary ray of every pixel, reference-order walk with a visit log ------------
+struct ProbeParams {
+    DevScene sc;
+    int32_t tex_w, tex_h, x0, y0, w, h;
+    uint32_t flags;
+    int32_t visit_cap;
+    int32_t* hit_prim;
+    double* hit_t;
+    int32_t* hit_leaf;
+    uint32_t* visit_log;
+    uint32_t* visit_count;
+};
+
+__global__ __launch_bounds__(256) void probe_kernel(ProbeParams Q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q.w * Q.h) return;
+    RenderParams P;
+    P.sc = Q.sc, P.tex_w = Q.tex_w, P.tex_h = Q.tex_h, P.flags = Q.flags;
+    int x, y;
+    map_pixel(P, Q.x0 + i % Q.w, Q.y0 + i / Q.w, x, y);
+    d3 d = emit(Q.sc, x, y);
+    if (Q.flags & RT_F_NORMALIZE_PRIMARY) d = unit(d);
+    Counters ctr;
+    uint32_t n = 0;
+    uint32_t* log = Q.visit_log ? Q.visit_log + (size_t)i * Q.visit_cap : nullptr;
+    Hit h = log ? scene_closest<true, true>(Q.sc, Q.flags, Q.sc.camO, d, ctr, log, (uint32_t)Q.visit_cap, n)
+                : scene_closest<true, false>(Q.sc, Q.flags, Q.sc.camO, d, ctr, nullptr, 0, n);
+    Q.hit_prim[i] = h.prim;
+    Q.hit_t[i] = h.dist;
+    Q.hit_leaf[i] = h.leaf;
+    if (Q.visit_count) Q.visit_count[i] = n;
+}
+
+// ================================= host side ====================================================
+static thread_local hipStream_t g_stream = nullptr;
+
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return rt_fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct rt_scene {
+    int device = 0;
+    DevScene dev{};
+    void* slab = nullptr;
+    size_t slab_bytes = 0;
+    uint32_t* queue = nullptr;             // work-queue head
+    unsigned long long* counters = nullptr;  // CTR_COUNT work counters
+    uint8_t* image = nullptr;              // staging image for host destinations
+    size_t image_bytes = 0;
+    Tile* tiles = nullptr;                 // tile list + prefix of the current call
+    uint32_t* prefix = nullptr;
+    size_t tiles_cap = 0;
+    int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int desc_cam_w = 0, desc_cam_h = 0;
+};
+
+extern "C" int rt_init(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return rt_fail(RT_ERR_NOGPU, "no HIP device visible");
+    if (device < 0 || device >= n) return rt_fail(RT_ERR_INVALID, "rt_init: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return rt_fail(RT_ERR_NOGPU, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    return RT_OK;
+}
+
+extern "C" int rt_set_stream(void* hip_stream) {
+    g_stream = (hipStream_t)hip_stream;
+    return RT_OK;
+}
+
+static bool link_ok(const rt_scene_desc* d, uint32_t from_pre, uint32_t ref, bool allow_end) {
+    if (ref == RT_REF_END) return allow_end;
+    uint32_t pre;
+    if (ref & RT_REF_LEAF) {
+        uint32_t i = ref & ~RT_REF_LEAF;
+        if (i >= d->n_leaves) return false;
+        pre = d->leaves[i].preorder;
+    } else {
+        if (ref >= d->n_nodes) return false;
+        pre = d->nodes[ref].preorder;
+    }
+    return pre > from_pre;  // links only go forward in pre-order, so every walk terminates
+}
+
+static int validate_desc(const rt_scene_desc* d) {
+    if (!d) return rt_fail(RT_ERR_INVALID, "scene description is null");
+    if (d->n_primitives < 0 || d->n_lights < 0 || d->n_textures < 0 || d->n_meshes < 0)
+        return rt_fail(RT_ERR_INVALID, "negative count in scene description");
+    if ((d->n_primitives && !d->primitives) || (d->n_lights && !d->lights) || (d->n_textures && !d->textures) ||
+        (d->n_meshes && !d->meshes) || (d->n_nodes && !d->nodes) || (d->n_leaves && !d->leaves))
+        return rt_fail(RT_ERR_INVALID, "null array in scene description");
+    if ((int)(16 * d->camera.shade_quality) < 1) return rt_fail(RT_ERR_INVALID, "camera shade_quality must give at least one light sample (16*shade_quality >= 1)");
+    if (d->camera.W <= 0 || d->camera.H <= 0) return rt_fail(RT_ERR_INVALID, "camera W/H must be positive");
+    for (int i = 0; i < d->n_textures; i++)
+        if (d->textures[i].width <= 0 || d->textures[i].height <= 0 || !d->textures[i].rgb) return rt_fail(RT_ERR_INVALID, "bad texture");
+    for (int i = 0; i < d->n_primitives; i++) {
+        const rt_primitive& p = d->primitives[i];
+        if (p.type < RT_PRIM_SPHERE || p.type > RT_PRIM_MESH) return rt_fail(RT_ERR_INVALID, "unknown primitive type");
+        if (p.material.texture >= d->n_textures) return rt_fail(RT_ERR_INVALID, "texture index out of range");
+        if (p.type == RT_PRIM_MESH && (p.u.mesh.mesh < 0 || p.u.mesh.mesh >= d->n_meshes)) return rt_fail(RT_ERR_INVALID, "mesh index out of range");
+        if (p.type == RT_PRIM_BEZIER && (p.u.bezier.degree > RT_BEZIER_MAX_CTRL - 1)) return rt_fail(RT_ERR_LIMIT, "bezier degree too large");
+    }
+    for (int i = 0; i < d->n_lights; i++) {
+        const rt_light& l = d->lights[i];
+        if (l.type < RT_LIGHT_POINT || l.type > RT_LIGHT_SPHERE) return rt_fail(RT_ERR_INVALID, "unknown light type");
+        if (l.light_primitive >= d->n_primitives) return rt_fail(RT_ERR_INVALID, "light primitive index out of range");
+    }
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        const rt_bvh_node& n = d->nodes[i];
+        if (!link_ok(d, n.preorder, n.left, false) || !link_ok(d, n.preorder, n.skip, true)) return rt_fail(RT_ERR_INVALID, "BVH node link out of range or not forward");
+    }
+    for (uint32_t i = 0; i < d->n_leaves; i++)
+        if (!link_ok(d, d->leaves[i].preorder, d->leaves[i].skip, true)) return rt_fail(RT_ERR_INVALID, "BVH leaf link out of range or not forward");
+    for (int i = 0; i < d->n_meshes; i++) {
+        uint32_t r = d->meshes[i].root;
+        if (r == RT_REF_END) continue;
+        if ((r & RT_REF_LEAF) ? ((r & ~RT_REF_LEAF) >= d->n_leaves) : (r >= d->n_nodes)) return rt_fail(RT_ERR_INVALID, "mesh root out of range");
+    }
+    return RT_OK;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->slab) (void)hipFree(s->slab);
+    if (s->queue) (void)hipFree(s->queue);
+    if (s->counters) (void)hipFree(s->counters);
+    if (s->image) (void)hipFree(s->image);
+    if (s->tiles) (void)hipFree(s->tiles);
+    if (s->prefix) (void)hipFree(s->prefix);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
+    if (!out) return rt_fail(RT_ERR_INVALID, "rt_scene_create: null out pointer");
+    *out = nullptr;
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return rt_fail(RT_ERR_NOGPU, "no HIP device visible");
+    rt_scene* s = new rt_scene;
+    struct Guard {
+        rt_scene* s;
+        ~Guard() { if (s) rt_scene_destroy(s); }
+    } guard{s};
+    HIPCHK(hipGetDevice(&s->device));
+
+    // one slab: lights | primitives | primitive extras | nodes | leaves | texels, one copy
+    std::vector<DevPrimX> px((size_t)d->n_primitives);
+    std::vector<uint32_t> tex_off((size_t)d->n_textures);
+    size_t texel_bytes = 0;
+    for (int i = 0; i < d->n_textures; i++) {
+        tex_off[i] = (uint32_t)texel_bytes;
+        texel_bytes += align_up((size_t)d->textures[i].width * d->textures[i].height * 3, 16);
+    }
+    if (texel_bytes >= (1ull << 32)) return rt_fail(RT_ERR_LIMIT, "more than 4 GiB of textures");
+    for (int i = 0; i < d->n_primitives; i++) {
+        const rt_primitive& p = d->primitives[i];
+        DevPrimX& x = px[i];
+        x.root = RT_REF_END, x.tex_w = x.tex_h = 0, x.tex_off = 0, x.cull_scale = 0;
+        if (p.material.texture >= 0) {
+            const rt_texture& t = d->textures[p.material.texture];
+            x.tex_w = t.width, x.tex_h = t.height, x.tex_off = tex_off[p.material.texture];
+        }
+        if (p.type == RT_PRIM_MESH) {
+            const rt_mesh& m = d->meshes[p.u.mesh.mesh];
+            x.root = m.root;
+            double sc = 0;
+            if (m.root != RT_REF_END && !(m.root & RT_REF_LEAF)) {
+                const rt_bvh_node& n = d->nodes[m.root];
+                for (int k = 0; k < 3; k++) sc = std::fmax(sc, std::fmax(std::fabs(n.bmin[k]), std::fabs(n.bmax[k])));
+            } else if (m.root != RT_REF_END) {
+                const rt_bvh_leaf& lf = d->leaves[m.root & ~RT_REF_LEAF];
+                const double c[9] = {lf.O1.x, lf.O1.y, lf.O1.z, lf.O2.x, lf.O2.y, lf.O2.z, lf.O3.x, lf.O3.y, lf.O3.z};
+                for (double v : c) sc = std::fmax(sc, std::fabs(v));
+            }
+            x.cull_scale = 3.0 * sc;
+        }
+    }
+    size_t off_l = 0;
+    size_t off_p = align_up(off_l + sizeof(rt_light) * d->n_lights, 256);
+    size_t off_x = align_up(off_p + sizeof(rt_primitive) * d->n_primitives, 256);
+    size_t off_n = align_up(off_x + sizeof(DevPrimX) * d->n_primitives, 256);
+    size_t off_f = align_up(off_n + sizeof(rt_bvh_node) * (size_t)d->n_nodes, 256);
+    size_t off_t = align_up(off_f + sizeof(rt_bvh_leaf) * (size_t)d->n_leaves, 256);
+    s->slab_bytes = align_up(off_t + texel_bytes, 256) + 256;
+    std::vector<uint8_t> host(s->slab_bytes, 0);
+    if (d->n_lights) std::memcpy(&host[off_l], d->lights, sizeof(rt_light) * d->n_lights);
+    if (d->n_primitives) std::memcpy(&host[off_p], d->primitives, sizeof(rt_primitive) * d->n_primitives);
+    if (d->n_primitives) std::memcpy(&host[off_x], px.data(), sizeof(DevPrimX) * d->n_primitives);
+    if (d->n_nodes) std::memcpy(&host[off_n], d->nodes, sizeof(rt_bvh_node) * (size_t)d->n_nodes);
+    if (d->n_leaves) std::memcpy(&host[off_f], d->leaves, sizeof(rt_bvh_leaf) * (size_t)d->n_leaves);
+    for (int i = 0; i < d->n_textures; i++)
+        std::memcpy(&host[off_t + tex_off[i]], d->textures[i].rgb, (size_t)d->textures[i].width * d->textures[i].height * 3);
+    HIPCHK(hipMalloc(&s->slab, s->slab_bytes));
+    HIPCHK(hipMemcpy(s->slab, host.data(), s->slab_bytes, hipMemcpyHostToDevice));
+    uint8_t* base = (uint8_t*)s->slab;
+    DevScene& v = s->dev;
+    v.bg_top = d3{d->background_top.x, d->background_top.y, d->background_top.z};
+    v.bg_bottom = d3{d->background_bottom.x, d->background_bottom.y, d->background_bottom.z};
+    v.camO = d3{d->camera.O.x, d->camera.O.y, d->camera.O.z};
+    v.camN = d3{d->camera.N.x, d->camera.N.y, d->camera.N.z};
+    v.camDx = d3{d->camera.Dx.x, d->camera.Dx.y, d->camera.Dx.z};
+    v.camDy = d3{d->camera.Dy.x, d->camera.Dy.y, d->camera.Dy.z};
+    v.cam_w = d->camera.W, v.cam_h = d->camera.H;
+    s->desc_cam_w = d->camera.W, s->desc_cam_h = d->camera.H;
+    v.shade_n = (int)(16 * d->camera.shade_quality);
+    v.n_lights = d->n_lights, v.n_prims = d->n_primitives;
+    v.lights = (const rt_light*)(base + off_l);
+    v.prims = (const rt_primitive*)(base + off_p);
+    v.primx = (const DevPrimX*)(base + off_x);
+    v.nodes = (const rt_bvh_node*)(base + off_n);
+    v.leaves = (const rt_bvh_leaf*)(base + off_f);
+    v.texels = base + off_t;
+
+    HIPCHK(hipMalloc(&s->queue, 256));
+    HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * CTR_COUNT));
+    HIPCHK(hipEventCreate(&s->ev0));
+    HIPCHK(hipEventCreate(&s->ev1));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, s->device));
+    s->cus = prop.multiProcessorCount;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->blocks_per_cu_fast, render_kernel<false>, 256, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->blocks_per_cu_strict, render_kernel<true>, 256, 0));
+    if (s->blocks_per_cu_fast < 1) s->blocks_per_cu_fast = 1;
+    if (s->blocks_per_cu_strict < 1) s->blocks_per_cu_strict = 1;
+    guard.s = nullptr;
+    *out = s;
+    return RT_OK;
+}
+
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+static int check_common(rt_scene* s, const rt_settings* st, int tex_w, int tex_h) {
+    if (!s || !st) return rt_fail(RT_ERR_INVALID, "null scene or settings");
+    if (tex_w <= 0 || tex_h <= 0 || tex_w > 32768 || tex_h > 32768) return rt_fail(RT_ERR_INVALID, "image size out of range");
+    if (st->spp < 1 || st->spp > 65536) return rt_fail(RT_ERR_INVALID, "samples per pixel must be in [1, 65536]");
+    return RT_OK;
+}
+
+// Render the given tiles into `dst` (device image).  Fills kernel time and counters.
+static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, const std::vector<Tile>& tiles,
+                        uint8_t* dst, rt_stats* stats) {
+    const int ppt = st->spp >= 64 ? 1 : 64 / st->spp;
+    std::vector<uint32_t> prefix(tiles.size() + 1, 0);
+    uint64_t pixels = 0, tasks = 0;
+    for (size_t i = 0; i < tiles.size(); i++) {
+        const Tile& t = tiles[i];
+        uint64_t slots = (uint64_t)((t.w + 7) / 8) * ((t.h + 7) / 8) * 64;
+        prefix[i] = (uint32_t)tasks;
+        tasks += (slots + ppt - 1) / ppt;
+        pixels += (uint64_t)t.w * t.h;
+        if (tasks >= (1ull << 31)) return rt_fail(RT_ERR_LIMIT, "too many tasks in one call");
+    }
+    prefix[tiles.size()] = (uint32_t)tasks;
+    if (tiles.size() > s->tiles_cap) {
+        if (s->tiles) (void)hipFree(s->tiles);
+        if (s->prefix) (void)hipFree(s->prefix);
+        s->tiles = nullptr, s->prefix = nullptr, s->tiles_cap = 0;
+        size_t cap = tiles.size() + 64;
+        HIPCHK(hipMalloc(&s->tiles, cap * sizeof(Tile)));
+        HIPCHK(hipMalloc(&s->prefix, (cap + 1) * sizeof(uint32_t)));
+        s->tiles_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(s->tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(s->prefix, prefix.data(), prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
+    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CTR_COUNT, g_stream));
+
+    RenderParams P;
+    P.sc = s->dev;
+    P.sc.cam_w = cam_w > 0 ? cam_w : s->desc_cam_w;
+    P.sc.cam_h = cam_h > 0 ? cam_h : s->desc_cam_h;
+    P.tex_w = tex_w, P.tex_h = tex_h, P.spp = st->spp, P.dof = st->dof_enabled ? 1 : 0;
+    P.focal = st->focal_distance, P.aperture = st->aperture;
+    P.k0 = (uint32_t)st->seed, P.k1 = (uint32_t)(st->seed >> 32), P.flags = st->flags;
+    P.n_tiles = (int)tiles.size(), P.ppt = ppt, P.n_tasks = (uint32_t)tasks;
+    P.tiles = s->tiles, P.tile_prefix = s->prefix, P.queue = s->queue, P.out = dst, P.counters = s->counters;
+
+    const bool strict = (st->flags & RT_F_STRICT_TRAVERSAL) != 0;
+    const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
+    uint64_t want_blocks = (tasks + 3) / 4;
+    uint64_t grid = (uint64_t)s->cus * bpc;
+    if (grid > want_blocks) grid = want_blocks;
+    if (grid < 1) grid = 1;
+    HIPCHK(hipEventRecord(s->ev0, g_stream));
+    if (tasks > 0) {
+        if (strict) hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        else hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(s->ev1, g_stream));
+    unsigned long long c[CTR_COUNT];
+    HIPCHK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    if (stats) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        stats->kernel_ms = ms;
+        stats->pixels = pixels;
+        stats->rays_primary = pixels * (uint64_t)st->spp;
+        stats->rays_secondary = c[CTR_SECONDARY], stats->rays_shadow = c[CTR_SHADOW];
+        stats->nodes_visited = c[CTR_NODES], stats->tris_tested = c[CTR_TRIS];
+        stats->shaded_hits = c[CTR_SHADED], stats->texture_fetches = c[CTR_TEXFETCH];
+    }
+    return RT_OK;
+}
+
+static int ensure_image(rt_scene* s, size_t bytes) {
+    if (s->image_bytes >= bytes) return RT_OK;
+    if (s->image) (void)hipFree(s->image);
+    s->image = nullptr, s->image_bytes = 0;
+    HIPCHK(hipMalloc(&s->image, bytes));
+    s->image_bytes = bytes;
+    return RT_OK;
+}
+
+static int render_common(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, const std::vector<Tile>& tiles,
+                         uint8_t* rgba, rt_stats* stats) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (!rgba) return rt_fail(RT_ERR_INVALID, "null output image");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t bytes = (size_t)tex_w * tex_h * 4;
+    int rc;
+    if (is_device_ptr(rgba)) {
+        rc = launch_tiles(s, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba, stats);
+        if (rc) return rc;
+    } else {
+        rc = ensure_image(s, bytes);
+        if (rc) return rc;
+        rc = launch_tiles(s, st, tex_w, tex_h, cam_w, cam_h, tiles, s->image, stats);
+        if (rc) return rc;
+        // copy back only the rows of the rendered rectangles; other pixels of the caller's image stay
+        for (const Tile& t : tiles) {
+            const size_t o = ((size_t)t.y0 * tex_w + t.x0) * 4;
+            HIPCHK(hipMemcpy2DAsync(rgba + o, (size_t)tex_w * 4, s->image + o, (size_t)tex_w * 4, (size_t)t.w * 4, (size_t)t.h,
+                                    hipMemcpyDeviceToHost, g_stream));
+        }
+        HIPCHK(hipStreamSynchronize(g_stream));
+    }
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
+extern "C" int rt_render_tile(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, int x0, int y0, int w,
+                              int h, uint8_t* rgba, rt_stats* stats) {
+    int rc = check_common(s, st, tex_w, tex_h);
+    if (rc) return rc;
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > tex_w || y0 + h > tex_h)
+        return rt_fail(RT_ERR_INVALID, "rectangle does not lie inside the image");
+    std::vector<Tile> tiles{Tile{x0, y0, w, h}};
+    return render_common(s, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba, stats);
+}
+
+extern "C" int rt_render_frame(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, int tile, int part,
+                               int n_parts, uint8_t* rgba, rt_stats* stats) {
+    int rc = check_common(s, st, tex_w, tex_h);
+    if (rc) return rc;
+    if (tile <= 0 || (tile & 7) || n_parts <= 0 || part < 0 || part >= n_parts)
+        return rt_fail(RT_ERR_INVALID, "tile must be a positive multiple of 8 and 0 <= part < n_parts");
+    std::vector<Tile> tiles;
+    const int tx = (tex_w + tile - 1) / tile, ty = (tex_h + tile - 1) / tile;
+    for (int j = 0; j < ty; j++)
+        for (int i = 0; i < tx; i++) {
+            if ((j * tx + i) % n_parts != part) continue;
+            Tile t{i * tile, j * tile, std::min(tile, tex_w - i * tile), std::min(tile, tex_h - j * tile)};
+            tiles.push_back(t);
+        }
+    if (n_parts == 1) tiles.assign(1, Tile{0, 0, tex_w, tex_h});  // one rectangle: no partial 8x8 blocks at tile seams
+    if (tiles.empty()) {
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        return RT_OK;
+    }
+    return render_common(s, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba, stats);
+}
+
+extern "C" int rt_trace_primary(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, int x0, int y0, int w,
+                                int h, int32_t* hit_prim, double* hit_t, int32_t* hit_leaf, uint32_t* visit_log, uint32_t* visit_count,
+                                int visit_cap) {
+    int rc = check_common(s, st, tex_w, tex_h);
+    if (rc) return rc;
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > tex_w || y0 + h > tex_h)
+        return rt_fail(RT_ERR_INVALID, "rectangle does not lie inside the image");
+    if (!hit_prim || !hit_t || !hit_leaf) return rt_fail(RT_ERR_INVALID, "null output array");
+    if (visit_log && visit_cap <= 0) return rt_fail(RT_ERR_INVALID, "visit_cap must be positive when a visit log is requested");
+    HIPCHK(hipSetDevice(s->device));
+    const size_t n = (size_t)w * h;
+    const size_t b_prim = align_up(n * 4, 256), b_t = align_up(n * 8, 256), b_leaf = align_up(n * 4, 256), b_cnt = align_up(n * 4, 256);
+    const size_t b_log = visit_log ? align_up(n * (size_t)visit_cap * 4, 256) : 0;
+    uint8_t* buf = nullptr;
+    HIPCHK(hipMalloc(&buf, b_prim + b_t + b_leaf + b_cnt + b_log));
+    ProbeParams Q;
+    Q.sc = s->dev;
+    Q.sc.cam_w = cam_w > 0 ? cam_w : s->desc_cam_w;
+    Q.sc.cam_h = cam_h > 0 ? cam_h : s->desc_cam_h;
+    Q.tex_w = tex_w, Q.tex_h = tex_h, Q.x0 = x0, Q.y0 = y0, Q.w = w, Q.h = h, Q.flags = st->flags, Q.visit_cap = visit_cap;
+    Q.hit_t = (double*)buf;
+    Q.hit_prim = (int32_t*)(buf + b_t);
+    Q.hit_leaf = (int32_t*)(buf + b_t + b_prim);
+    Q.visit_count = (uint32_t*)(buf + b_t + b_prim + b_leaf);
+    Q.visit_log = visit_log ? (uint32_t*)(buf + b_t + b_prim + b_leaf + b_cnt) : nullptr;
+    hipLaunchKernelGGL(probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, Q);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(hit_t, Q.hit_t, n * 8, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hit_prim, Q.hit_prim, n * 4, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hit_leaf, Q.hit_leaf, n * 4, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && visit_count) e = hipMemcpyAsync(visit_count, Q.visit_count, n * 4, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess && visit_log) e = hipMemcpyAsync(visit_log, Q.visit_log, n * (size_t)visit_cap * 4, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return rt_fail(RT_ERR_DEVICE, std::string("rt_trace_primary: ") + hipGetErrorString(e));
+    return RT_OK;
+}

@@ -1,0 +1,86 @@
+// Device-side double3 arithmetic and the counter-based RNG.
+//
+// Every expression keeps the operation order of the reference (helper_math.h:546-570,833-853,
+// 1138-1158,1302-1305,1613-1616,1789-1806,1873-1900 for the CUDA path; CR/vector3.cpp:14-173 for
+// the CPU path) and this file is compiled with -ffp-contract=off so no multiply-add is fused:
+// hit distances and hit ids are then bit-identical with a CPU evaluation of the same formulas.
+// normalize() divides by sqrt() (CR/vector3.cpp:128-131) instead of multiplying by rsqrt()
+// (helper_math.h:1681-1685), whose CUDA implementation is not correctly rounded.
+#ifndef RT_MATH_HPP
+#define RT_MATH_HPP
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_amd.h"
+
+struct d3 {
+    double x, y, z;
+};
+#define DEV static __device__ __forceinline__
+
+DEV d3 D3(double x, double y, double z) { return d3{x, y, z}; }
+DEV d3 D3(const rt_vec3& v) { return d3{v.x, v.y, v.z}; }
+DEV d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+DEV d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+DEV d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }
+DEV d3 operator*(d3 a, double k) { return d3{a.x * k, a.y * k, a.z * k}; }
+DEV d3 operator/(d3 a, double k) { return d3{a.x / k, a.y / k, a.z / k}; }
+DEV d3 mulv(d3 a, d3 b) { return d3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEV d3 cross(d3 a, d3 b) { return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+DEV double module(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+DEV d3 unit(d3 a) { return a / module(a); }
+DEV d3 vertical(d3 a) {
+    d3 r = cross(a, D3(0, 0, 1));
+    if (fabs(r.x) < RT_EPS && fabs(r.y) < RT_EPS && fabs(r.z) < RT_EPS) return D3(1, 0, 0);
+    return unit(r);
+}
+DEV d3 reflect(d3 i, d3 n) { return i - n * (2 * dot(n, i)); }
+DEV d3 refract(d3 V, d3 N, double n) {
+    V = unit(V);
+    double cosI = -dot(N, V), cosT2 = 1 - (n * n) * (1 - cosI * cosI);
+    if (cosT2 > RT_EPS) return V * n + N * (n * cosI - sqrt(cosT2));
+    return reflect(V, N);
+}
+
+// ---- Philox4x32-10, counter = (pixel, sample, block, 0), key = seed ----------------------
+// Replaces the curand state of CR/RayTracer.cu:9-21 (shared memory written by another launch,
+// indexed by threadIdx.x only).  Draw i of a (pixel, sample) is word i%4 of block i/4, so the
+// image does not depend on how pixels are spread over lanes, tiles or GPUs.
+DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
+        c[0] = n0, c[1] = l1, c[2] = n2, c[3] = l0;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+}
+// uniform float in (0, 1] from 32 random bits: curand_uniform's mapping, which frand() returns
+DEV float u32_to_unit(uint32_t x) { return (float)x * 2.3283064365386963e-10f + 1.1641532182693481e-10f; }
+
+// Draws always come in pairs at even indices (jitter u,v; aperture x,y; light sample a,b;
+// blur x,y), so both values of a pair live in one Philox block.
+DEV void frand_pair(uint32_t k0, uint32_t k1, uint32_t pixel, uint32_t sample, uint32_t draw, float& a, float& b) {
+    uint32_t c[4] = {pixel, sample, draw >> 2, 0u};
+    philox4x32_10(c, k0, k1);
+    bool hi = (draw & 2u) != 0;
+    a = u32_to_unit(hi ? c[2] : c[0]);
+    b = u32_to_unit(hi ? c[3] : c[1]);
+}
+
+// ---- wave64 helpers ------------------------------------------------------------------------
+DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+DEV int rank_in(unsigned long long mask) {  // number of set bits of `mask` below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+DEV double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+DEV d3 shfl_d3(d3 v, int src) { return d3{__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)}; }
+DEV unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#endif

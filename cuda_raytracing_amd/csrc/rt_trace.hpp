@@ -1,0 +1,504 @@
+// Device-side intersectors, stackless BVH traversal and shading.
+//
+// What each function computes is the reference's (citations per function; CR/ =
+// CUDA_RayTracing/ in the reference tree); how it is organised is not: primitives and lights
+// are wave-uniform records fetched through the scalar cache, the per-mesh BVH is walked without
+// a stack through skip links, and shadow rays are spread over the lanes of the wave.
+#ifndef RT_TRACE_HPP
+#define RT_TRACE_HPP
+#include "rt_math.hpp"
+
+// Per-primitive data the device needs beyond rt_primitive.
+struct DevPrimX {
+    uint32_t root;      // mesh: ref of the BVH root (RT_REF_END if empty / not a mesh)
+    int32_t tex_w, tex_h;
+    uint32_t tex_off;   // byte offset of the texture in the texel pool
+    double cull_scale;  // mesh: |coordinates| bound used to size the culling safety margin
+};
+
+struct DevScene {
+    d3 bg_top, bg_bottom, camO, camN, camDx, camDy;
+    int32_t cam_w, cam_h, shade_n, n_lights, n_prims;
+    const rt_light* __restrict__ lights;
+    const rt_primitive* __restrict__ prims;
+    const DevPrimX* __restrict__ primx;
+    const rt_bvh_node* __restrict__ nodes;
+    const rt_bvh_leaf* __restrict__ leaves;
+    const uint8_t* __restrict__ texels;
+};
+
+struct Hit {  // CR/Primitive.cuh:107-113
+    d3 N, C;
+    double dist;
+    int32_t prim;   // -1 = no hit
+    int32_t leaf;   // leaf pre-order index inside the mesh, -1 otherwise
+    bool front;
+};
+
+struct Counters {  // per-lane work counters, flushed once per wave
+    uint32_t rays_secondary, rays_shadow, nodes, tris, shaded, texfetch;
+};
+
+// ---- analytic primitives -------------------------------------------------------------------
+// Each returns the hit distance or RT_BIG_DIST.  `full` = also produce C, N, front (closest-hit
+// rays); shadow rays only need the distance.
+
+// CR/Collision.cu:155-176, CR/primitive.cpp:109-138
+template <bool FULL>
+DEV double sphere_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
+    d3 V = unit(d), O = D3(p.u.sphere.O), P = o - O;
+    double b = -dot(P, V), R = p.u.sphere.R;
+    double det = b * b - dot(P, P) + R * R;
+    if (!(det > RT_EPS)) return RT_BIG_DIST;
+    det = sqrt(det);
+    double x1 = b - det, x2 = b + det;
+    if (x2 < RT_EPS) return RT_BIG_DIST;
+    bool front = x1 > RT_EPS;
+    double dist = front ? x1 : x2;
+    if (FULL) {
+        h.front = front;
+        h.C = o + V * dist;
+        h.N = unit(h.C - O);
+        if (!front) h.N = -h.N;
+    }
+    return dist;
+}
+
+// CR/Collision.cu:177-196, CR/primitive.cpp:159-175
+template <bool FULL>
+DEV double plane_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
+    d3 V = unit(d), N = unit(D3(p.u.plane.N));
+    double den = dot(N, V);
+    if (!(fabs(den) >= RT_EPS)) return RT_BIG_DIST;
+    double t = dot(N * p.u.plane.R - o, N) / den;
+    if (!(t >= RT_EPS)) return RT_BIG_DIST;
+    if (FULL) {
+        h.C = o + V * t;
+        h.front = den < 0;
+        h.N = h.front ? N : -N;
+    }
+    return t;
+}
+
+// CR/Collision.cu:197-256, CR/primitive.cpp:192-227
+template <bool FULL>
+DEV double square_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
+    d3 V = unit(d), Dx = D3(p.u.square.Dx), Dy = D3(p.u.square.Dy), O = D3(p.u.square.O);
+    d3 N = unit(cross(Dx, Dy));
+    double den = dot(N, V);
+    if (fabs(den) < RT_EPS) return RT_BIG_DIST;
+    double t = dot(O - o, N) / den;
+    if (t < RT_EPS) return RT_BIG_DIST;
+    d3 P = o + V * t;
+    double lx = dot(Dx, Dx), ly = dot(Dy, Dy);
+    double x2 = fabs(dot(P - O, Dx)), y2 = fabs(dot(P - O, Dy));
+    if (x2 > lx || y2 > ly) return RT_BIG_DIST;
+    if (FULL) {
+        h.front = den < 0;
+        h.C = P;
+        h.N = h.front ? N : -N;
+    }
+    return t;
+}
+
+// CR/Collision.cu:3-107.  front = false marks a body hit, true a cap hit (the texture lookup
+// reuses it that way, CR/Primitive.cu:56).
+template <bool FULL>
+DEV double cylinder_hit(d3 O1, d3 O2, double R, d3 o, d3 d, Hit& h) {
+    d3 V = unit(d);
+    {
+        d3 dd = O2 - O1, m = o - O1;
+        double r2 = R * R;
+        d3 dN = unit(dd);
+        d3 mP = cross(m, dN), vP = cross(V, dN);
+        double a = dot(vP, vP), b = 2.0 * dot(vP, mP), c = dot(mP, mP) - r2;
+        double det = b * b - 4 * a * c;
+        if (det >= 0) {
+            det = sqrt(det);
+            double t0 = (-b - det) / (2.0 * a), t1 = (-b + det) / (2.0 * a);
+            double t = fmin(t0, t1);
+            if (t < 0) t = fmax(t0, t1);
+            if (t >= 0) {
+                d3 P = o + V * t;
+                double u = dot(P - O1, dN);
+                if (u >= 0 && u <= module(dd)) {
+                    if (FULL) {
+                        h.C = P;
+                        h.front = false;
+                        h.N = unit(P - (O1 + dN * u));
+                    }
+                    return t;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int cap = 0; cap < 2; cap++) {  // cap at O2 first, then cap at O1
+        d3 N = cap == 0 ? unit(O1 - O2) : unit(O2 - O1);
+        d3 Q0 = cap == 0 ? O2 : O1;
+        double den = dot(N, V);
+        if (fabs(den) >= RT_EPS) {
+            double t = dot(Q0 - o, N) / den;
+            if (t >= RT_EPS) {
+                d3 P = o + V * t, Q = P - Q0;
+                if (dot(Q, Q) <= R * R) {
+                    if (FULL) {
+                        h.C = P;
+                        h.front = true;
+                        h.N = den < 0 ? N : -N;
+                    }
+                    return t;
+                }
+            }
+        }
+    }
+    return RT_BIG_DIST;
+}
+
+// CR/Collision_Bezier.cu:200-240: the profile as a stack of cylinders, including the way
+// `closest` trails one accepted hit behind.
+template <bool FULL>
+DEV double bezier_stacked_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
+    double closest = 1e10, cur = RT_BIG_DIST;
+    d3 O1 = D3(p.u.bezier.O1), axis = unit(D3(p.u.bezier.O2) - O1);
+    for (int i = 0; i < p.u.bezier.degree; i++) {
+        d3 p1, p2;
+        double R;
+        if (i == 0) {
+            p1 = O1;
+            p2 = O1 + axis * p.u.bezier.Z[0];
+            R = p.u.bezier.R_c;
+        } else {
+            p1 = O1 + axis * p.u.bezier.Z[i - 1];
+            p2 = O1 + axis * p.u.bezier.Z[i];
+            R = p.u.bezier.R[i];
+        }
+        Hit tmp;
+        double t = cylinder_hit<FULL>(p1, p2, R, o, d, tmp);
+        if (t < RT_BIG_DIST && t < closest) {
+            closest = cur;
+            cur = t;
+            if (FULL) h.C = tmp.C, h.N = tmp.N, h.front = tmp.front;
+        }
+    }
+    return cur;
+}
+
+// CR/Collision.cu:110-149,267-282 (standalone triangle; the normal is not flipped)
+template <bool FULL>
+DEV double triangle_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
+    d3 V1 = D3(p.u.triangle.O1), e1 = D3(p.u.triangle.O2) - V1, e2 = D3(p.u.triangle.O3) - V1;
+    d3 hh = cross(d, e2);
+    double a = dot(e1, hh);
+    if (fabs(a) < RT_EPS) return RT_BIG_DIST;
+    double f = 1.0 / a;
+    d3 s = o - V1;
+    double u = f * dot(s, hh);
+    if (u < 0.0 || u > 1.0) return RT_BIG_DIST;
+    d3 q = cross(s, e1);
+    double v = f * dot(d, q);
+    if (v < 0.0 || u + v > 1.0) return RT_BIG_DIST;
+    double t = f * dot(e2, q);
+    if (!(t > RT_EPS)) return RT_BIG_DIST;
+    if (FULL) {
+        h.C = o + d * t;
+        h.N = unit(cross(e1, e2));
+        h.front = dot(d, h.N) < 0;
+    }
+    return t;
+}
+
+// ---- mesh: stackless BVH walk ----------------------------------------------------------------
+// CR/Collision_Mesh.cu:3-17 slab test, :19-63 Moeller-Trumbore, :65-80 depth-first order
+// (left subtree, then right subtree, both always).  The reference recurses; here every item
+// carries the ref of the next item in pre-order after its subtree ("skip"), so "box missed"
+// and "leaf done" are one pointer step and no stack exists.
+//
+// STRICT walks exactly the reference's sequence.  Otherwise two prunings apply, neither of
+// which can change the result:
+//   * a subtree whose box is entered beyond `t_limit` (the distance that still matters: the
+//     best hit so far for closest-hit rays, the light distance for shadow rays) or lies wholly
+//     behind the ray origin is skipped - every triangle inside is farther than t_limit or
+//     behind.  The slab distances carry rounding error, so the comparison is relaxed by
+//     `margin`, a bound on that error for this ray;
+//   * ANYHIT stops at the first triangle closer than t_limit (a shadow ray only asks whether
+//     one exists).
+// Ties keep the reference's winner: leaves are met in the same pre-order and a later leaf
+// replaces the best only if strictly closer (CR/Collision_Mesh.cu:71).
+struct MeshResult {
+    double t;       // closest accepted t (RT_BIG_DIST if none)
+    uint32_t leaf;  // ref of the winning leaf
+};
+
+template <bool STRICT, bool ANYHIT, bool LOG>
+DEV MeshResult mesh_walk(const DevScene& sc, uint32_t root, d3 o, d3 d, double t_limit, double cull_scale, Counters& ctr,
+                         uint32_t* log, uint32_t log_cap, uint32_t& log_n, uint32_t log_tag) {
+    MeshResult res{RT_BIG_DIST, RT_REF_END};
+    const double t_exact = t_limit;  // ANYHIT: the caller's occlusion test is t_exact - t > 1e-6
+    d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    double margin = 0.0;
+    if (!STRICT) {
+        // |error| of a slab distance <= ~4 ulp * (|box| + |o|) * |1/d|; infinite 1/d (an exactly
+        // axis-parallel ray) yields exact +-inf / NaN slab values and needs no margin.
+        double m = 0.0;
+        if (fabs(inv.x) < 1e300) m = fmax(m, fabs(inv.x));
+        if (fabs(inv.y) < 1e300) m = fmax(m, fabs(inv.y));
+        if (fabs(inv.z) < 1e300) m = fmax(m, fabs(inv.z));
+        margin = 1e-13 * (cull_scale + fabs(o.x) + fabs(o.y) + fabs(o.z)) * m;
+        t_limit = t_limit + margin + 1e-9 * fabs(t_limit);
+    }
+    uint32_t ref = root;
+    while (ref != RT_REF_END) {
+        // interior items until every lane that is still walking stands on a leaf
+        while (!(ref & RT_REF_LEAF)) {
+            const rt_bvh_node& n = sc.nodes[ref];
+            ctr.nodes++;
+            if (LOG) {
+                if (log_n < log_cap) log[log_n] = log_tag | n.preorder;
+                log_n++;
+            }
+            double t0x = (n.bmin[0] - o.x) * inv.x, t1x = (n.bmax[0] - o.x) * inv.x;
+            double t0y = (n.bmin[1] - o.y) * inv.y, t1y = (n.bmax[1] - o.y) * inv.y;
+            double t0z = (n.bmin[2] - o.z) * inv.z, t1z = (n.bmax[2] - o.z) * inv.z;
+            double tminmax = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
+            double tmaxmin = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
+            bool enter = tminmax <= tmaxmin;
+            if (!STRICT) enter = enter && !(tminmax > t_limit) && !(tmaxmin < -margin);
+            ref = enter ? n.left : n.skip;
+        }
+        if (ref == RT_REF_END) break;
+        const rt_bvh_leaf& lf = sc.leaves[ref & ~RT_REF_LEAF];
+        ctr.nodes++;
+        ctr.tris++;
+        if (LOG) {
+            if (log_n < log_cap) log[log_n] = log_tag | lf.preorder;
+            log_n++;
+        }
+        uint32_t here = ref;
+        ref = lf.skip;
+        d3 O1 = D3(lf.O1), e1 = D3(lf.O2) - O1, e2 = D3(lf.O3) - O1;
+        d3 p = cross(d, e2);
+        double det = dot(e1, p);
+        if (fabs(det) < RT_EPS) continue;
+        double idet = 1.0 / det;
+        d3 tv = o - O1;
+        double u = dot(tv, p) * idet;
+        if (u < 0.0 || u > 1.0) continue;
+        d3 q = cross(tv, e1);
+        double v = dot(d, q) * idet;
+        if (v < 0.0 || u + v > 1.0) continue;
+        double t0 = dot(e2, q) * idet;
+        if (t0 <= RT_EPS) continue;
+        if (t0 < res.t) {
+            res.t = t0;
+            res.leaf = here;
+            if (!STRICT) {
+                if (ANYHIT) {
+                    if (t_exact - t0 > RT_EPS) break;  // this triangle already decides the caller's test
+                } else {
+                    double lim = t0 + margin + 1e-9 * fabs(t0);
+                    if (lim < t_limit) t_limit = lim;
+                }
+            }
+        }
+    }
+    return res;
+}
+
+// CR/Collision_Mesh.cu:45-60: hit record of the winning leaf (normal as CR/primitive.cpp:457 stores it)
+DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double t0, Hit& h) {
+    const rt_bvh_leaf& lf = sc.leaves[leafref & ~RT_REF_LEAF];
+    d3 O1 = D3(lf.O1), e1 = D3(lf.O2) - O1, e2 = D3(lf.O3) - O1;
+    h.C = o + d * t0;
+    d3 N = unit(cross(e1, e2));
+    h.front = dot(d, N) < 0;
+    h.N = h.front ? N : -N;
+    h.leaf = (int32_t)lf.preorder;
+}
+
+// ---- closest hit over the scene: CR/Scene.cu:3-21, CR/Scene.cpp:27-38 ---------------------
+template <bool STRICT, bool LOG>
+DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint32_t* log, uint32_t log_cap,
+                      uint32_t& log_n) {
+    Hit best;
+    best.prim = -1, best.leaf = -1, best.dist = RT_BIG_DIST, best.front = false;
+    best.N = D3(0, 0, 0), best.C = D3(0, 0, 0);
+    const bool later_wins = (flags & RT_F_TIE_LATER_WINS) != 0;
+    for (int i = 0; i < sc.n_prims; i++) {
+        const rt_primitive& p = sc.prims[i];
+        Hit tmp;
+        tmp.leaf = -1;
+        double t = RT_BIG_DIST;
+        switch (p.type) {
+            case RT_PRIM_SPHERE: t = sphere_hit<true>(p, o, d, tmp); break;
+            case RT_PRIM_PLANE: t = plane_hit<true>(p, o, d, tmp); break;
+            case RT_PRIM_SQUARE: t = square_hit<true>(p, o, d, tmp); break;
+            case RT_PRIM_CYLINDER: t = cylinder_hit<true>(D3(p.u.cylinder.O1), D3(p.u.cylinder.O2), p.u.cylinder.R, o, d, tmp); break;
+            case RT_PRIM_BEZIER: t = bezier_stacked_hit<true>(p, o, d, tmp); break;
+            case RT_PRIM_TRIANGLE: t = triangle_hit<true>(p, o, (flags & RT_F_MESH_RAW_DIR) ? d : unit(d), tmp); break;
+            case RT_PRIM_MESH: {
+                d3 dm = (flags & RT_F_MESH_RAW_DIR) ? d : unit(d);
+                // only hits that can still win matter: t < best (or < best + 1e-6 under the later-wins rule)
+                double lim = later_wins ? best.dist + RT_EPS : best.dist;
+                MeshResult r = mesh_walk<STRICT, false, LOG>(sc, sc.primx[i].root, o, dm, lim, sc.primx[i].cull_scale, ctr, log,
+                                                             log_cap, log_n, (uint32_t)p.u.mesh.mesh << 24);
+                t = r.t;
+                if (t < RT_BIG_DIST) mesh_fill_hit(sc, r.leaf, o, dm, t, tmp);
+                break;
+            }
+            default: break;
+        }
+        if (t < RT_BIG_DIST) {
+            bool take = later_wins ? (t - best.dist < RT_EPS) : (t < best.dist);
+            if (take) {
+                best.N = tmp.N, best.C = tmp.C, best.front = tmp.front, best.leaf = tmp.leaf;
+                best.dist = t;
+                best.prim = i;
+            }
+        }
+    }
+    return best;
+}
+
+// ---- one shadow ray: CR/Shade.cu:36-46,64-75,94-105, CR/Light.cpp:35-40,67-78 ----------------
+// true = nothing between C and target.  A primitive occludes if dist - its_hit_distance > 1e-6.
+template <bool STRICT>
+DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, Counters& ctr) {
+    d3 V = target - C;
+    double dist = module(V);
+    uint32_t dummy_n = 0;
+    const bool self_skip = (flags & RT_F_SHADOW_SELF_SKIP) != 0;
+    for (int j = 0; j < sc.n_prims; j++) {
+        if (self_skip && j == crashed) continue;
+        if (j == light_prim) continue;
+        const rt_primitive& p = sc.prims[j];
+        Hit tmp;
+        double t = RT_BIG_DIST;
+        switch (p.type) {
+            case RT_PRIM_SPHERE: t = sphere_hit<false>(p, C, V, tmp); break;
+            case RT_PRIM_PLANE: t = plane_hit<false>(p, C, V, tmp); break;
+            case RT_PRIM_SQUARE: t = square_hit<false>(p, C, V, tmp); break;
+            case RT_PRIM_CYLINDER: t = cylinder_hit<false>(D3(p.u.cylinder.O1), D3(p.u.cylinder.O2), p.u.cylinder.R, C, V, tmp); break;
+            case RT_PRIM_BEZIER: t = bezier_stacked_hit<false>(p, C, V, tmp); break;
+            case RT_PRIM_TRIANGLE: t = triangle_hit<false>(p, C, (flags & RT_F_MESH_RAW_DIR) ? V : unit(V), tmp); break;
+            case RT_PRIM_MESH: {
+                d3 dm = (flags & RT_F_MESH_RAW_DIR) ? V : unit(V);
+                t = mesh_walk<STRICT, true, false>(sc, sc.primx[j].root, C, dm, dist, sc.primx[j].cull_scale, ctr, nullptr, 0, dummy_n, 0).t;
+                break;
+            }
+            default: break;
+        }
+        if (dist - t > RT_EPS) return false;
+    }
+    return true;
+}
+
+// ---- textures: CR/bmp.cpp:133-150 (double taps), CR/Primitive.cu:85-115 (8-bit taps) --------
+DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevPrimX& px, double u, double v) {
+    const int H = px.tex_h, W = px.tex_w;
+    const bool u8 = (flags & RT_F_TEX_U8_TAPS) != 0;
+    double U = (u - (u8 ? (double)floorf((float)u) : floor(u))) * H;
+    double Vv = (v - (u8 ? (double)floorf((float)v) : floor(v))) * W;
+    int U1 = u8 ? (int)floorf((float)(U - RT_EPS)) : (int)floor(U - RT_EPS), U2 = U1 + 1;
+    int V1 = u8 ? (int)floorf((float)(Vv - RT_EPS)) : (int)floor(Vv - RT_EPS), V2 = V1 + 1;
+    double ru = U2 - U, rv = V2 - Vv;
+    if (U1 < 0) U1 = H - 1;
+    if (U2 == H) U2 = 0;
+    if (V1 < 0) V1 = W - 1;
+    if (V2 == W) V2 = 0;
+    if (U1 < 0 || U1 >= H) U1 = 0;  // finite u,v never get here; a NaN must not read outside the texture
+    if (U2 < 0 || U2 >= H) U2 = 0;
+    if (V1 < 0 || V1 >= W) V1 = 0;
+    if (V2 < 0 || V2 >= W) V2 = 0;
+    const uint8_t* base = sc.texels + px.tex_off;
+    const uint8_t* t11 = base + ((size_t)U1 * W + V1) * 3;
+    const uint8_t* t12 = base + ((size_t)U1 * W + V2) * 3;
+    const uint8_t* t21 = base + ((size_t)U2 * W + V1) * 3;
+    const uint8_t* t22 = base + ((size_t)U2 * W + V2) * 3;
+    double w1a = ru, w1b = rv, w2a = ru, w2b = 1 - rv, w3a = 1 - ru, w3b = rv, w4a = 1 - ru, w4b = 1 - rv;
+    double out[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (u8) {
+            double s = 0;
+            s += (double)(uint8_t)(int)((double)(uint8_t)(int)(t11[k] * w1a) * w1b);
+            s += (double)(uint8_t)(int)((double)(uint8_t)(int)(t12[k] * w2a) * w2b);
+            s += (double)(uint8_t)(int)((double)(uint8_t)(int)(t21[k] * w3a) * w3b);
+            s += (double)(uint8_t)(int)((double)(uint8_t)(int)(t22[k] * w4a) * w4b);
+            out[k] = s / 256.0;
+        } else {
+            double s = 0;
+            s = s + t11[k] / 256.0 * w1a * w1b;
+            s = s + t12[k] / 256.0 * w2a * w2b;
+            s = s + t21[k] / 256.0 * w3a * w3b;
+            s = s + t22[k] / 256.0 * w4a * w4b;
+            out[k] = s;
+        }
+    }
+    return D3(out[0], out[1], out[2]);
+}
+
+// CR/Primitive.cu:16-83, CR/primitive.cpp:140-147,177-181,229-233
+DEV d3 texture_color(const DevScene& sc, uint32_t flags, const Hit& c, Counters& ctr) {
+    const rt_primitive& p = sc.prims[c.prim];
+    const DevPrimX& px = sc.primx[c.prim];
+    double u, v;
+    switch (p.type) {
+        case RT_PRIM_SPHERE: {
+            d3 I = unit(c.C - D3(p.u.sphere.O));
+            double a = acos(-dot(I, D3(p.u.sphere.De)));
+            double b = acos(fmin(fmax(dot(I, D3(p.u.sphere.Dc)) / sin(a), -1.0), 1.0));
+            u = a / M_PI, v = b / 2 / M_PI;
+            if (dot(I, cross(D3(p.u.sphere.Dc), D3(p.u.sphere.De))) < 0) v = 1 - v;
+            break;
+        }
+        case RT_PRIM_PLANE: {
+            d3 Dx = D3(p.u.plane.Dx), Dy = D3(p.u.plane.Dy);
+            u = dot(c.C, Dx) / dot(Dx, Dx);
+            v = dot(c.C, Dy) / dot(Dy, Dy);
+            break;
+        }
+        case RT_PRIM_SQUARE: {
+            d3 Dx = D3(p.u.square.Dx), Dy = D3(p.u.square.Dy);
+            d3 b = (flags & RT_F_SQUARE_UV_NO_ORIGIN) ? c.C : c.C - D3(p.u.square.O);
+            u = dot(b, Dx) / dot(Dx, Dx) / 2 + 0.5;
+            v = dot(b, Dy) / dot(Dy, Dy) / 2 + 0.5;
+            break;
+        }
+        case RT_PRIM_CYLINDER: {
+            d3 O1 = D3(p.u.cylinder.O1), O2 = D3(p.u.cylinder.O2);
+            if (!c.front) {
+                d3 cp = c.C - O1;
+                double ang = atan2(cp.z, cp.x);
+                if (ang < 0) ang += 2 * M_PI;
+                u = ang / (2 * M_PI);
+                v = dot(c.C - O1, unit(O2 - O1)) / module(O2 - O1);
+            } else {
+                d3 cc = module(c.C - O1) < module(c.C - O2) ? O1 : O2;
+                d3 l = c.C - cc;
+                u = l.x / (2.0 * p.u.cylinder.R) + 0.5;
+                v = l.z / (2.0 * p.u.cylinder.R) + 0.5;
+            }
+            break;
+        }
+        default:  // Bezier / triangle / mesh have no texture mapping: Color() (CR/primitive.cpp:290-295,339-342,372-375)
+            return D3(0, 0, 0);
+    }
+    ctr.texfetch++;
+    return smooth_color(sc, flags, px, u, v);
+}
+
+// Point on a light for sample draws (a, b): CR/Shade.cu:3-21
+DEV d3 light_sample(const rt_light& L, float fa, float fb) {
+    if (L.type == RT_LIGHT_SQUARE) {
+        double a = (double)(2 * fa) - 1.0, b = (double)(2 * fb) - 1.0;
+        return D3(L.O) + D3(L.Dx) * a + D3(L.Dy) * b;
+    }
+    double z = 2.0 * fa - 1.0;
+    double th = fb * 2.0 * M_PI;
+    double r = sqrt(1.0 - z * z);
+    double x = r * cos(th), y = r * sin(th);
+    return D3(L.O) + D3(L.R * x, L.R * y, L.R * z);
+}
+
+#endif

@@ -1,0 +1,84 @@
+"""Device scene + render calls: object wrapper over the device half of the C ABI.
+
+`DeviceScene` plays the role of the reference's `SceneContainer` (CR/Renderer.h:19-26): it owns
+the uploaded scene and frees it on close.  Rendering goes through `rt_render_tile` /
+`rt_render_frame` only; there is no CPU path here, and construction fails if the HIP library or a
+gfx950 device is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class DeviceScene:
+    def __init__(self, host_scene, device=0):
+        import torch  # noqa: F401  plumbing: loads the HIP runtime that librt_amd.so then binds to
+
+        self._lib = abi.load_library()
+        abi.check(self._lib.rt_init(device))
+        self.device = device
+        self._h = C.c_void_p()
+        abi.check(self._lib.rt_scene_create(host_scene.desc_ptr, C.byref(self._h)))
+        self.host = host_scene
+
+    def close(self):
+        if self._h:
+            self._lib.rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_handle):
+        abi.check(self._lib.rt_set_stream(C.c_void_p(hip_stream_handle)))
+
+    @staticmethod
+    def _ptr(out):
+        """Destination pointer of a numpy array (host) or a torch CUDA uint8 tensor (device)."""
+        if isinstance(out, np.ndarray):
+            assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"]
+            return out.ctypes.data
+        assert out.is_contiguous() and out.element_size() == 1
+        return out.data_ptr()
+
+    def render_tile(self, st, tex_w, tex_h, rect, cam=None, out=None):
+        """launchRayTraceKernel (CR/RayTracer.cuh:12): render rectangle (x0, y0, w, h)."""
+        x0, y0, w, h = rect
+        cw, ch = cam or (tex_w, tex_h)
+        if out is None:
+            out = np.zeros((tex_h, tex_w, 4), dtype=np.uint8)
+        stats = abi.Stats()
+        abi.check(self._lib.rt_render_tile(self._h, C.byref(st), tex_w, tex_h, cw, ch, x0, y0, w, h, self._ptr(out), C.byref(stats)))
+        return out, stats
+
+    def render_frame(self, st, tex_w, tex_h, cam=None, tile=32, part=0, n_parts=1, out=None):
+        """launchRayTraceKernelParallel (CR/RayTracer.cuh:13) for the tiles owned by `part`."""
+        cw, ch = cam or (tex_w, tex_h)
+        if out is None:
+            out = np.zeros((tex_h, tex_w, 4), dtype=np.uint8)
+        stats = abi.Stats()
+        abi.check(self._lib.rt_render_frame(self._h, C.byref(st), tex_w, tex_h, cw, ch, tile, part, n_parts, self._ptr(out), C.byref(stats)))
+        return out, stats
+
+    def trace_primary(self, st, tex_w, tex_h, rect=None, cam=None, visit_cap=0):
+        x0, y0, w, h = rect or (0, 0, tex_w, tex_h)
+        cw, ch = cam or (tex_w, tex_h)
+        hit = np.zeros((h, w), dtype=np.int32)
+        t = np.zeros((h, w), dtype=np.float64)
+        leaf = np.zeros((h, w), dtype=np.int32)
+        log = np.zeros((h, w, max(visit_cap, 1)), dtype=np.uint32)
+        cnt = np.zeros((h, w), dtype=np.uint32)
+        abi.check(self._lib.rt_trace_primary(self._h, C.byref(st), tex_w, tex_h, cw, ch, x0, y0, w, h, hit.ctypes.data, t.ctypes.data,
+                                             leaf.ctypes.data, log.ctypes.data if visit_cap else None, cnt.ctypes.data, visit_cap))
+        return hit, t, leaf, log, cnt

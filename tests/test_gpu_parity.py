@@ -1,0 +1,196 @@
+"""GPU parity: the HIP render path (through the C ABI) against the CPU oracle and the committed
+golden fixtures from the reference's own CPU renderer.
+
+Bars: primary-ray hit primitive, hit leaf, hit distance and BVH visit order bit-exact; ray / node /
+triangle counts exact in strict traversal; colour within 1/255 per channel (the only inexact
+operations on the colour path are libm calls - pow, exp, sin, cos, acos, atan2 - whose device and
+host implementations may differ in the last ulp), with the number of pixels that differ at all
+bounded."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+from cuda_raytracing_amd import abi
+from cuda_raytracing_amd.host import HostScene
+from helpers import GOLD, SCENES, same_double
+
+pytestmark = pytest.mark.gpu
+
+COLOUR_TOL = 1          # max abs error, in 8-bit levels
+MAX_DIFF_FRACTION = 0.002  # pixels allowed to differ by that one level
+
+
+def scene(name):
+    return HostScene(os.path.join(SCENES, name + ".txt"))
+
+
+def device_scene(hs):
+    from cuda_raytracing_amd.device import DeviceScene
+    return DeviceScene(hs, device=0)
+
+
+def assert_colour_close(img, ref, what=""):
+    d = np.abs(img[..., :3].astype(np.int32) - ref[..., :3].astype(np.int32))
+    assert d.max() <= COLOUR_TOL, f"{what}: max abs colour error {d.max()} levels at {np.unravel_index(d.argmax(), d.shape)}"
+    frac = float((d.max(-1) > 0).mean())
+    assert frac <= MAX_DIFF_FRACTION, f"{what}: {frac:.4%} of pixels differ"
+    assert np.array_equal(img[..., 3], ref[..., 3])
+
+
+@pytest.mark.parametrize("name", ["c1_purple_sphere", "t_cpu_features", "t_inside"])
+def test_cpu_ref_mode_against_reference_fixtures(name):
+    """Config 1 family: what the reference's CPU renderer computed (golden) vs the GPU."""
+    g = np.load(os.path.join(GOLD, "render", name + ".npz"))
+    hs = scene(name)
+    W, H = hs.desc.camera.W, hs.desc.camera.H
+    st = orc.settings(spp=1, flags=abi.RT_MODE_CPU_REF)
+    with device_scene(hs) as ds:
+        hit, t, _, _, _ = ds.trace_primary(st, W, H)
+        img, stats = ds.render_frame(st, W, H)
+    assert np.array_equal(hit, g["hit"].astype(np.int32)), "primary hit ids differ from the reference"
+    step = int(g["lattice"]) if "lattice" in g else 1
+    assert same_double(t[::step, ::step], g["dist"]), "primary hit distances differ from the reference (must be bit-exact)"
+    ref = np.concatenate([g["rgb8"], np.full(g["rgb8"].shape[:2] + (1,), 255, np.uint8)], -1)
+    assert_colour_close(img, ref, name)
+    assert stats.rays_primary == W * H
+
+
+@pytest.mark.parametrize("name,flags,spp,dof", [
+    ("t_icosa", abi.RT_MODE_GPU_REF, 4, True),
+    ("t_icosa", abi.RT_MODE_CPU_REF, 2, False),
+    ("t_cpu_features", abi.RT_MODE_GPU_REF, 3, True),
+    ("t_grammar_quirks", abi.RT_MODE_GPU_REF, 1, False),
+])
+def test_full_render_against_oracle(name, flags, spp, dof):
+    hs = scene(name)
+    W, H = 96, 72
+    st = orc.settings(spp=spp, dof=dof, focal=9.0, aperture=1.5, seed=11, flags=flags | abi.RT_F_STRICT_TRAVERSAL)
+    ref, _, ostats = orc.render(hs, st, W, H)
+    with device_scene(hs) as ds:
+        img, stats = ds.render_frame(st, W, H)
+        st.flags = flags  # pruned traversal: same image, same rays
+        fast, fstats = ds.render_frame(st, W, H)
+    assert_colour_close(img, ref, name)
+    for k in ("rays_primary", "rays_secondary", "rays_shadow", "shaded_hits", "texture_fetches", "nodes_visited", "tris_tested", "pixels"):
+        assert getattr(stats, k) == getattr(ostats, k), (k, getattr(stats, k), getattr(ostats, k))
+    assert np.array_equal(fast, img), "pruned traversal changed the image"
+    assert fstats.rays == stats.rays and fstats.nodes_visited <= stats.nodes_visited
+
+
+@pytest.mark.parametrize("name,rect", [("t_icosa", (0, 0, 96, 72)), ("c4_lucy", (60, 30, 40, 24)), ("c5_final", (40, 20, 48, 32))])
+def test_primary_hits_and_visit_order_bit_exact(name, rect):
+    """Hit ids and BVH visit order of primary rays, reference-order traversal."""
+    hs = scene(name)
+    W, H = 160, 96
+    cap = 1024
+    st = orc.settings(flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
+    o_hit, o_t, o_leaf, o_log, o_cnt = orc.trace_primary(hs, st, W, H, rect=rect, visit_cap=cap)
+    with device_scene(hs) as ds:
+        hit, t, leaf, log, cnt = ds.trace_primary(st, W, H, rect=rect, visit_cap=cap)
+    assert np.array_equal(hit, o_hit) and np.array_equal(leaf, o_leaf)
+    assert same_double(t, o_t)
+    assert np.array_equal(cnt, o_cnt), "number of BVH items visited differs"
+    assert cnt.max() > 0
+    k = np.minimum(cnt, cap)
+    valid = np.arange(cap)[None, None, :] < k[..., None]
+    assert np.array_equal(np.where(valid, log, 0), np.where(valid, o_log, 0)), "BVH visit order differs"
+
+
+@pytest.mark.parametrize("name,W,H,spp", [("c4_lucy", 160, 90, 2), ("c5_final", 128, 96, 1)])
+def test_mesh_scenes_against_oracle_and_pruned_equals_strict(name, W, H, spp):
+    hs = scene(name)
+    base = abi.RT_MODE_GPU_REF
+    st = orc.settings(spp=spp, dof=True, focal=1.35 if name == "c4_lucy" else 168.0, aperture=1.0 if name == "c4_lucy" else 150.0,
+                      seed=2, flags=base | abi.RT_F_STRICT_TRAVERSAL)
+    ref, _, ostats = orc.render(hs, st, W, H)
+    with device_scene(hs) as ds:
+        strict, sstats = ds.render_frame(st, W, H)
+        st.flags = base
+        fast, fstats = ds.render_frame(st, W, H)
+    assert_colour_close(strict, ref, name)
+    assert sstats.rays == ostats.rays and sstats.nodes_visited == ostats.nodes_visited and sstats.tris_tested == ostats.tris_tested
+    assert np.array_equal(fast, strict), "pruned traversal changed the image"
+    assert fstats.rays == sstats.rays
+    assert fstats.nodes_visited < sstats.nodes_visited
+
+
+@pytest.mark.parametrize("spp", [1, 3, 32, 64, 100])
+def test_sample_counts(spp):
+    """1 lane per sample: groups that do not divide 64 and counts above 64 (several passes)."""
+    hs = scene("t_icosa")
+    W, H = 40, 24
+    st = orc.settings(spp=spp, dof=True, focal=9.0, aperture=2.0, seed=spp, flags=abi.RT_MODE_GPU_REF)
+    ref, _, ostats = orc.render(hs, st, W, H)
+    with device_scene(hs) as ds:
+        img, stats = ds.render_frame(st, W, H)
+    assert_colour_close(img, ref, f"spp={spp}")
+    assert stats.rays == ostats.rays
+
+
+FLAGS = [abi.RT_F_NORMALIZE_PRIMARY, abi.RT_F_SKY_Y, abi.RT_F_TIE_LATER_WINS, abi.RT_F_SHADOW_SELF_SKIP, abi.RT_F_SQUARE_UV_NO_ORIGIN,
+         abi.RT_F_TEX_U8_TAPS, abi.RT_F_PIXEL_MAP_TRUNC, abi.RT_F_MESH_RAW_DIR]
+
+
+@pytest.mark.parametrize("flag", FLAGS)
+def test_each_semantics_flag(flag):
+    """Every CPU-vs-CUDA difference bit, toggled alone on top of both presets."""
+    hs = scene("t_icosa")
+    tex, cam = (90, 66), (96, 72)  # texture != viewport so the pixel map matters
+    with device_scene(hs) as ds:
+        for base in (abi.RT_MODE_CPU_REF, abi.RT_MODE_GPU_REF):
+            st = orc.settings(spp=2, seed=9, flags=base ^ flag)
+            ref, _, _ = orc.render(hs, st, *tex, cam=cam)
+            img, _ = ds.render_frame(st, *tex, cam=cam)
+            assert_colour_close(img, ref, f"flag {flag:#x} on base {base:#x}")
+
+
+def test_partition_and_rectangles_do_not_change_the_image():
+    hs = scene("t_icosa")
+    W, H = 100, 70
+    st = orc.settings(spp=4, dof=True, focal=9.0, aperture=1.0, seed=4, flags=abi.RT_MODE_GPU_REF)
+    with device_scene(hs) as ds:
+        full, fs = ds.render_frame(st, W, H)
+        merged = np.zeros_like(full)
+        rays = 0
+        for part in range(3):
+            _, s = ds.render_frame(st, W, H, tile=16, part=part, n_parts=3, out=merged)
+            rays += s.rays
+        assert np.array_equal(merged, full) and rays == fs.rays
+        rect = (13, 9, 51, 37)
+        canvas = np.full_like(full, 7)
+        ds.render_tile(st, W, H, rect, out=canvas)
+        x0, y0, w, h = rect
+        assert np.array_equal(canvas[y0:y0 + h, x0:x0 + w], full[y0:y0 + h, x0:x0 + w])
+        canvas[y0:y0 + h, x0:x0 + w] = 7
+        assert (canvas == 7).all(), "pixels outside the rectangle were touched"
+        again, _ = ds.render_frame(st, W, H)
+        assert np.array_equal(again, full), "two renders of the same frame differ"
+
+
+def test_device_destination_and_stream():
+    import torch
+    hs = scene("c1_purple_sphere")
+    W, H = 160, 120
+    st = orc.settings(spp=1, flags=abi.RT_MODE_CPU_REF)
+    with device_scene(hs) as ds:
+        host, _ = ds.render_frame(st, W, H)
+        s = torch.cuda.Stream()
+        ds.set_stream(s.cuda_stream)
+        dev = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        ds.render_frame(st, W, H, out=dev)
+        ds.set_stream(0)
+    assert np.array_equal(dev.cpu().numpy(), host)
+
+
+def test_errors_are_codes_not_exits():
+    hs = scene("c1_purple_sphere")
+    st = orc.settings()
+    with device_scene(hs) as ds:
+        with pytest.raises(abi.RtError) as e:
+            ds.render_tile(st, 64, 48, (60, 0, 10, 10))
+        assert e.value.code == -1 and "rectangle" in str(e.value)
+        st.spp = 0
+        with pytest.raises(abi.RtError):
+            ds.render_frame(st, 64, 48)
