@@ -232,7 +232,9 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
                             frand_pair(P.k0, P.k1, pixel, smp, draw, fx, fy);
                             draw += 2;
                             double x = fx, y = fy;
-                            double bxk = x * cos(y), byk = x * sin(y);
+                            double sn, cs;
+                            det_sincos(y, sn, cs);
+                            double bxk = x * cs, byk = x * sn;
                             nd = rv + bx * bxk + by * byk;
                         }
                     } else {  // CalnRefraction, CR/Scene_Material.cu:101-118
@@ -291,8 +293,11 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
 }
 
 // ---- the render kernel: CR/RayTracer.cu:40-94 --------------------------------------------------
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 2  // register budget: 512 / RT_WAVES_PER_SIMD VGPR+AGPR per lane
+#endif
 template <bool STRICT>
-__global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
+__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
     const int lane = lane_id();
     const DevScene& sc = P.sc;
     Counters ctr;
@@ -610,10 +615,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     s->cus = prop.multiProcessorCount;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->blocks_per_cu_fast, render_kernel<false>, 256, 0));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->blocks_per_cu_strict, render_kernel<true>, 256, 0));
-    if (s->blocks_per_cu_fast < 1) s->blocks_per_cu_fast = 1;
-    if (s->blocks_per_cu_strict < 1) s->blocks_per_cu_strict = 1;
+    // the kernels are built for RT_WAVES_PER_SIMD resident waves per SIMD = that many 256-thread blocks per CU
+    s->blocks_per_cu_fast = s->blocks_per_cu_strict = RT_WAVES_PER_SIMD;
     guard.s = nullptr;
     *out = s;
     return RT_OK;

@@ -43,6 +43,28 @@ DEV d3 refract(d3 V, d3 N, double n) {
     return reflect(V, N);
 }
 
+
+// sin/cos of the angles that steer rays (sphere-light samples CR/Shade.cu:8-21, fuzzy reflection
+// CR/Scene_Material.cu:19-27).  An explicit polynomial (Cody-Waite reduction by pi/2 + the fdlibm
+// kernel polynomials) instead of the device math library: the same expressions evaluated in the
+// same order on any IEEE-754 machine give the same bits, so ray directions - and with them every
+// visibility decision - can be reproduced exactly by a CPU check.  About one ulp for 0 <= x <= 2*pi.
+DEV void det_sincos(double x, double& sn, double& cs) {
+    int k = (int)(x * 6.36619772367581382433e-01 + 0.5);
+    double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    double z = r * r;
+    double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    double c = 1.0 - (0.5 * z - z * pc);
+    switch (k & 3) {
+        case 0: sn = s, cs = c; break;
+        case 1: sn = c, cs = -s; break;
+        case 2: sn = -s, cs = -c; break;
+        default: sn = -c, cs = s; break;
+    }
+}
+
 // ---- Philox4x32-10, counter = (pixel, sample, block, 0), key = seed ----------------------
 // Replaces the curand state of CR/RayTracer.cu:9-21 (shared memory written by another launch,
 // indexed by threadIdx.x only).  Draw i of a (pixel, sample) is word i%4 of block i/4, so the

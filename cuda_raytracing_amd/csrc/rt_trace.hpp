@@ -496,8 +496,9 @@ DEV d3 light_sample(const rt_light& L, float fa, float fb) {
     }
     double z = 2.0 * fa - 1.0;
     double th = fb * 2.0 * M_PI;
-    double r = sqrt(1.0 - z * z);
-    double x = r * cos(th), y = r * sin(th);
+    double r = sqrt(1.0 - z * z), sn, cs;
+    det_sincos(th, sn, cs);
+    double x = r * cs, y = r * sn;
     return D3(L.O) + D3(L.R * x, L.R * y, L.R * z);
 }
 

@@ -19,7 +19,8 @@
  *
  * Arithmetic: operation order follows the reference expression by expression; compile with
  * -ffp-contract=off.  Places where the .cu rounds through float (`float t`, sqrtf in length(),
- * sinf/cosf) are evaluated in double here, as the reference's CPU path does.
+ * sinf/cosf) are evaluated in double here, as the reference's CPU path does.  sin/cos of angles
+ * that steer rays come from det_sincos() below rather than libm (see there).
  */
 #include "rt_amd.h"
 
@@ -100,6 +101,29 @@ float orc_frand_at(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw
     g.next = draw;
     return frand(&g);
 }
+
+
+/* ---- sin/cos of the angles that steer rays (sphere-light samples, fuzzy reflection) ----------
+ * An explicit polynomial (Cody-Waite reduction by pi/2 + the fdlibm kernel polynomials), not
+ * libm, so that the device code - which evaluates the same expressions in the same order - gets
+ * bit-identical ray directions and therefore identical visibility decisions.  Accurate to about
+ * one ulp for the arguments that occur (0 <= x <= 2*pi). */
+static void det_sincos(double x, double* sn, double* cs) {
+    int k = (int)(x * 6.36619772367581382433e-01 + 0.5);        /* nearest multiple of pi/2 */
+    double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    double z = r * r;
+    double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    double c = 1.0 - (0.5 * z - z * pc);
+    switch (k & 3) {
+        case 0: *sn = s, *cs = c; break;
+        case 1: *sn = c, *cs = -s; break;
+        case 2: *sn = -s, *cs = -c; break;
+        default: *sn = -c, *cs = s; break;
+    }
+}
+void orc_det_sincos(double x, double* sn, double* cs) { det_sincos(x, sn, cs); }
 
 /* ---- per-call context -------------------------------------------------------------------- */
 typedef struct {
@@ -484,8 +508,9 @@ static double caln_shade(ctx_t* cx, rng_t* g, v3 C, int crashed, const rt_light*
             for (int i = 0; i < n; i++) { /* CR/Shade.cu:8-21 */
                 double z = 2.0 * frand(g) - 1.0;
                 double th = frand(g) * 2.0 * M_PI;
-                double r = sqrt(1.0 - z * z);
-                double x = r * cos(th), y = r * sin(th);
+                double r = sqrt(1.0 - z * z), sn, cs;
+                det_sincos(th, &sn, &cs);
+                double x = r * cs, y = r * sn;
                 v3 ro = add(L->O, V3(L->R * x, L->R * y, L->R * z));
                 shade += shadow_clear(cx, C, ro, crashed, L->light_primitive);
             }
@@ -535,7 +560,9 @@ static v3 caln_reflection(ctx_t* cx, rng_t* g, const col_t* c, v3 rv, int dep) {
     bx = mulk(bx, p->material.drefl);
     by = mulk(by, p->material.drefl);
     double x = frand(g), y = frand(g); /* CR/Scene_Material.cu:19-27 */
-    double bxk = x * cos(y), byk = x * sin(y);
+    double sn, cs;
+    det_sincos(y, &sn, &cs);
+    double bxk = x * cs, byk = x * sn;
     v3 fz = add(add(rv, mulk(bx, bxk)), mulk(by, byk));
     return mulk(mulv(trace_ray(cx, g, c->C, fz, dep + 1), p->material.color), p->material.refl);
 }
