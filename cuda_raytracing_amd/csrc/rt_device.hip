@@ -18,6 +18,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,7 +50,9 @@ struct RenderParams {
     unsigned long long* counters;
 };
 
-enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT };
+enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT,
+       // lane-utilisation probes, only counted in -DRT_UTIL_COUNTERS builds (printed by rt_render_* to stderr)
+       CTR_U_SHADOW_SLOTS = CTR_COUNT, CTR_U_SHADOW_ITEMS, CTR_U_TRACE_SLOTS, CTR_U_TRACE_ACTIVE, CTR_ALL };
 
 // ---- camera: CR/RayTracer.cu:52-61, CR/camera.cpp:57-59 -------------------------------------------
 DEV d3 emit(const DevScene& sc, double x, double y) {
@@ -84,11 +87,6 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
                       uint32_t smp, Counters& ctr) {
     const DevScene& sc = P.sc;
     const int lane = lane_id();
-    const int nshade = __popcll(mask);
-    const int my_rank = need ? rank_in(mask) : nshade + rank_in(~mask);
-    // lane r learns which lane owns shading slot r
-    const int owner_tbl = __builtin_amdgcn_ds_permute(my_rank << 2, lane);
-
     d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
     if (need) {
         const rt_material& m = sc.prims[h.prim].material;
@@ -98,33 +96,63 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
     }
     uint32_t off = 0;
     for (int l = 0; l < sc.n_lights; l++) {
-        const rt_light& L = sc.lights[l];
+        const rt_light RT_CONST& L = LIGHTS(sc)[l];
         const bool point = L.type == RT_LIGHT_POINT;
         const int n_l = point ? 1 : sc.shade_n;
-        const int total = nshade * n_l;
+        // Which lanes have shadow rays worth tracing for this lamp.  In reference-order mode all of
+        // them.  Otherwise not those whose result cannot matter (lamp behind the surface: the shade
+        // is only used when N.L > 1e-6, CR/Scene_Material.cu:52) and not those with nothing that
+        // could stand between the point and the lamp: every sample is then visible.
+        unsigned long long cand = ~0ull;
+        bool work = need;
         int cnt = 0;
+        if (need) ctr.rays_shadow += (uint32_t)n_l;
+        if (!STRICT && need) {
+            const d3 R = unit(d3{L.O.x, L.O.y, L.O.z} - h.C);
+            if (!(dot(R, h.N) > RT_EPS)) {
+                work = false;
+            } else {
+                cand = light_candidates(sc, P.flags, h.C, L);
+                if (P.flags & RT_F_SHADOW_SELF_SKIP) cand &= ~(h.prim < 64 ? 1ull << h.prim : 0ull);
+                if (L.light_primitive >= 0 && L.light_primitive < 64) cand &= ~(1ull << L.light_primitive);
+                if (cand == 0ull) work = false, cnt = n_l;
+            }
+        }
+        const unsigned long long wmask = __ballot(work);
+        const int nwork = __popcll(wmask);
+        const int my_rank = work ? rank_in(wmask) : nwork + rank_in(~wmask);
+        const int owner_tbl = __builtin_amdgcn_ds_permute(my_rank << 2, lane);  // lane r learns which lane owns slot r
+        const int total = nwork * n_l;
         for (int base = 0; base < total; base += 64) {
             const int item = base + lane;
             const bool act = item < total;
+#ifdef RT_UTIL_COUNTERS
+            ctr.u_shadow_slots++;
+            ctr.u_shadow_items += act ? 1u : 0u;
+#endif
             const int r = act ? item / n_l : 0;
             const int si = item - r * n_l;
             const int owner = __shfl(owner_tbl, r, 64);
             const d3 C = shfl_d3(h.C, owner);
             const int crashed = __shfl(h.prim, owner, 64);
             const uint32_t opix = __shfl(pixel, owner, 64), osmp = __shfl(smp, owner, 64), odraw = __shfl(draw, owner, 64);
+            const unsigned long long ocand = STRICT ? ~0ull : __shfl(cand, owner, 64);
             bool clear = false;
             if (act) {
-                d3 target = D3(L.O);
+                d3 target = d3{L.O.x, L.O.y, L.O.z};
+#ifdef RT_ABLATE_RNG
+                if (false) {
+#else
                 if (!point) {
+#endif
                     float fa, fb;
                     frand_pair(P.k0, P.k1, opix, osmp, odraw + off + 2u * (uint32_t)si, fa, fb);
                     target = light_sample(L, fa, fb);
                 }
-                ctr.rays_shadow++;
-                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ctr);
+                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, ctr);
             }
             const unsigned long long cm = __ballot(clear);
-            if (need) {
+            if (work) {
                 int lo = my_rank * n_l - base, hi = lo + n_l;
                 if (lo < 0) lo = 0;
                 if (hi > 64) hi = 64;
@@ -138,16 +166,17 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
             double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
             if (!(shade < RT_EPS)) {
                 const rt_material& m = sc.prims[h.prim].material;
-                d3 R = unit(D3(L.O) - h.C);
+                d3 R = unit(d3{L.O.x, L.O.y, L.O.z} - h.C);
+                const d3 Lc = d3{L.color.x, L.color.y, L.color.z};
                 double dt = dot(R, h.N);
                 if (dt > RT_EPS) {
                     if (m.diff > RT_EPS) {
                         double diff = m.diff * dt * shade;
-                        ret = ret + mulv(color, D3(L.color)) * diff;
+                        ret = ret + mulv(color, Lc) * diff;
                     }
                     if (m.spec > RT_EPS) {
                         double spec = m.spec * pow(dt, (double)RT_SPEC_POWER) * shade;
-                        ret = ret + mulv(color, D3(L.color)) * spec;
+                        ret = ret + mulv(color, Lc) * spec;
                     }
                 }
             }
@@ -178,6 +207,10 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
         h.prim = -1, h.leaf = -1, h.dist = RT_BIG_DIST, h.front = false, h.N = D3(0, 0, 0), h.C = D3(0, 0, 0);
         bool surface = false;
         d3 result = D3(0, 0, 0);
+#ifdef RT_UTIL_COUNTERS
+        ctr.u_trace_slots++;
+        ctr.u_trace_active += (tracing && sp + 1 <= RT_MAX_DEPTH) ? 1u : 0u;
+#endif
         if (tracing && sp + 1 <= RT_MAX_DEPTH) {
             if (sp > 0) ctr.rays_secondary++;
             h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log);
@@ -294,7 +327,7 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
 
 // ---- the render kernel: CR/RayTracer.cu:40-94 --------------------------------------------------
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 2  // register budget: 512 / RT_WAVES_PER_SIMD VGPR+AGPR per lane
+#define RT_WAVES_PER_SIMD 4  // register budget: 512 / RT_WAVES_PER_SIMD VGPR+AGPR per lane
 #endif
 template <bool STRICT>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
@@ -302,6 +335,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     const DevScene& sc = P.sc;
     Counters ctr;
     ctr.rays_secondary = ctr.rays_shadow = ctr.nodes = ctr.tris = ctr.shaded = ctr.texfetch = 0;
+#ifdef RT_UTIL_COUNTERS
+    ctr.u_shadow_slots = ctr.u_shadow_items = ctr.u_trace_slots = ctr.u_trace_active = 0;
+#endif
     const int spp = P.spp;
     const int group = spp <= 64 ? spp : 64;        // lanes per pixel within one pass
     const int passes = spp <= 64 ? 1 : (spp + 63) / 64;
@@ -375,9 +411,16 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
             *reinterpret_cast<uint32_t*>(P.out + (size_t)pixel * 4) = rgba;
         }
     }
+#ifdef RT_UTIL_COUNTERS
+    unsigned long long v[CTR_ALL] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch,
+                                     ctr.u_shadow_slots, ctr.u_shadow_items, ctr.u_trace_slots, ctr.u_trace_active};
+    const int n_ctr = CTR_ALL;
+#else
     unsigned long long v[CTR_COUNT] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch};
+    const int n_ctr = CTR_COUNT;
+#endif
 #pragma unroll
-    for (int i = 0; i < CTR_COUNT; i++) {
+    for (int i = 0; i < n_ctr; i++) {
         unsigned long long s = wave_sum_u64(v[i]);
         if (lane == 0 && s) atomicAdd(&P.counters[i], s);
     }
@@ -510,6 +553,127 @@ static int validate_desc(const rt_scene_desc* d) {
     return RT_OK;
 }
 
+
+// ---- host-side precomputation of DevGeom (same IEEE double operations, in the same order, as the
+// reference performs per ray; this file is compiled with -ffp-contract=off on the host too) -------
+namespace hostmath {
+struct h3 {
+    double x, y, z;
+};
+static h3 H(const rt_vec3& v) { return h3{v.x, v.y, v.z}; }
+static h3 operator+(h3 a, h3 b) { return h3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+static h3 operator-(h3 a, h3 b) { return h3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+static h3 operator*(h3 a, double k) { return h3{a.x * k, a.y * k, a.z * k}; }
+static h3 operator/(h3 a, double k) { return h3{a.x / k, a.y / k, a.z / k}; }
+static double hdot(h3 a, h3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static h3 hcross(h3 a, h3 b) { return h3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static double hmodule(h3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+static h3 hunit(h3 a) { return a / hmodule(a); }
+static void put(DevGeom& g, int i, h3 v) { g.f[i] = v.x, g.f[i + 1] = v.y, g.f[i + 2] = v.z; }
+}  // namespace hostmath
+
+static void set_ball(DevGeom& g, hostmath::h3 c, double r) {
+    hostmath::put(g, BND_C, c);
+    g.f[BND_R] = r * (1.0 + 1e-6) + 1e-9;  // inflated: the pre-test must never reject a true hit
+    if (!(g.f[BND_R] == g.f[BND_R]) || !(c.x == c.x) || !(c.y == c.y) || !(c.z == c.z)) g.f[BND_R] = 1e300;  // degenerate: never prune
+}
+
+static void cylinder_geom(DevGeom& g, hostmath::h3 O1, hostmath::h3 O2, double R) {
+    using namespace hostmath;
+    g.type = RT_PRIM_CYLINDER;
+    h3 dd = O2 - O1;
+    put(g, CYL_O1, O1), put(g, CYL_O2, O2);
+    put(g, CYL_DN, hunit(dd));
+    g.f[CYL_LEN] = hmodule(dd);
+    g.f[CYL_R2] = R * R;
+    put(g, CYL_NTOP, hunit(O1 - O2));
+    put(g, CYL_NBOT, hunit(O2 - O1));
+    double half = 0.5 * hmodule(dd);
+    set_ball(g, (O1 + O2) * 0.5, std::sqrt(half * half + R * R));
+}
+
+static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g, std::vector<DevGeom>& segs) {
+    using namespace hostmath;
+    std::memset(&g, 0, sizeof(g));
+    g.type = p.type;
+    g.f[BND_R] = 1e300;
+    switch (p.type) {
+        case RT_PRIM_SPHERE:
+            put(g, SPH_O, H(p.u.sphere.O));
+            g.f[SPH_R2] = p.u.sphere.R * p.u.sphere.R;
+            set_ball(g, H(p.u.sphere.O), std::fabs(p.u.sphere.R));
+            break;
+        case RT_PRIM_PLANE: {
+            h3 N = hunit(H(p.u.plane.N));
+            put(g, PLN_N, N), put(g, PLN_NR, N * p.u.plane.R);
+            break;
+        }
+        case RT_PRIM_SQUARE: {
+            h3 Dx = H(p.u.square.Dx), Dy = H(p.u.square.Dy);
+            put(g, SQR_O, H(p.u.square.O)), put(g, SQR_N, hunit(hcross(Dx, Dy))), put(g, SQR_DX, Dx), put(g, SQR_DY, Dy);
+            g.f[SQR_LX] = hdot(Dx, Dx), g.f[SQR_LY] = hdot(Dy, Dy);
+            set_ball(g, H(p.u.square.O), hmodule(Dx) + hmodule(Dy));
+            break;
+        }
+        case RT_PRIM_CYLINDER:
+            cylinder_geom(g, H(p.u.cylinder.O1), H(p.u.cylinder.O2), p.u.cylinder.R);
+            break;
+        case RT_PRIM_BEZIER: {  // segments of CR/Collision_Bezier.cu:206-222
+            h3 O1 = H(p.u.bezier.O1), axis = hunit(H(p.u.bezier.O2) - O1);
+            g.aux0 = (uint32_t)segs.size();
+            g.aux1 = p.u.bezier.degree > 0 ? p.u.bezier.degree : 0;
+            double tmin = 1e300, tmax = -1e300, rmax = 0;
+            for (int i = 0; i < g.aux1; i++) {
+                h3 p1 = i == 0 ? O1 : O1 + axis * p.u.bezier.Z[i - 1];
+                h3 p2 = O1 + axis * p.u.bezier.Z[i];
+                double R = i == 0 ? p.u.bezier.R_c : p.u.bezier.R[i];
+                DevGeom sg;
+                std::memset(&sg, 0, sizeof(sg));
+                cylinder_geom(sg, p1, p2, R);
+                segs.push_back(sg);
+                for (h3 e : {p1, p2}) {
+                    double t = hdot(e - O1, axis);
+                    tmin = std::fmin(tmin, t), tmax = std::fmax(tmax, t);
+                }
+                rmax = std::fmax(rmax, std::fabs(R));
+            }
+            if (g.aux1 > 0) {
+                double half = 0.5 * (tmax - tmin);
+                set_ball(g, O1 + axis * (0.5 * (tmin + tmax)), std::sqrt(half * half + rmax * rmax));
+            }
+            break;
+        }
+        case RT_PRIM_TRIANGLE: {
+            h3 V1 = H(p.u.triangle.O1), e1 = H(p.u.triangle.O2) - V1, e2 = H(p.u.triangle.O3) - V1;
+            put(g, TRI_V1, V1), put(g, TRI_E1, e1), put(g, TRI_E2, e2), put(g, TRI_N, hunit(hcross(e1, e2)));
+            set_ball(g, V1, std::fmax(hmodule(e1), hmodule(e2)));
+            break;
+        }
+        case RT_PRIM_MESH: {
+            const rt_mesh& m = d->meshes[p.u.mesh.mesh];
+            g.aux0 = m.root;
+            g.aux1 = p.u.mesh.mesh;
+            double sc = 0;
+            h3 lo{0, 0, 0}, hi{0, 0, 0};
+            if (m.root != RT_REF_END && !(m.root & RT_REF_LEAF)) {
+                const rt_bvh_node& n = d->nodes[m.root];
+                for (int k = 0; k < 3; k++) sc = std::fmax(sc, std::fmax(std::fabs(n.bmin[k]), std::fabs(n.bmax[k])));
+                lo = h3{n.bmin[0], n.bmin[1], n.bmin[2]}, hi = h3{n.bmax[0], n.bmax[1], n.bmax[2]};
+            } else if (m.root != RT_REF_END) {
+                const rt_bvh_leaf& lf = d->leaves[m.root & ~RT_REF_LEAF];
+                const double c[9] = {lf.O1.x, lf.O1.y, lf.O1.z, lf.O2.x, lf.O2.y, lf.O2.z, lf.O3.x, lf.O3.y, lf.O3.z};
+                for (double v : c) sc = std::fmax(sc, std::fabs(v));
+                lo = h3{std::fmin(c[0], std::fmin(c[3], c[6])), std::fmin(c[1], std::fmin(c[4], c[7])), std::fmin(c[2], std::fmin(c[5], c[8]))};
+                hi = h3{std::fmax(c[0], std::fmax(c[3], c[6])), std::fmax(c[1], std::fmax(c[4], c[7])), std::fmax(c[2], std::fmax(c[5], c[8]))};
+            }
+            g.f[MSH_SCALE] = 3.0 * sc;
+            set_ball(g, (lo + hi) * 0.5, 0.5 * hmodule(hi - lo));  // empty mesh: a point ball, never reached
+            break;
+        }
+        default: break;
+    }
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" void rt_scene_destroy(rt_scene* s) {
@@ -540,8 +704,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     } guard{s};
     HIPCHK(hipGetDevice(&s->device));
 
-    // one slab: lights | primitives | primitive extras | nodes | leaves | texels, one copy
+    // one slab: lights | geometry | Bezier segments | primitives | primitive extras | nodes | leaves | texels, one copy
     std::vector<DevPrimX> px((size_t)d->n_primitives);
+    std::vector<DevGeom> geom((size_t)d->n_primitives), segs;
     std::vector<uint32_t> tex_off((size_t)d->n_textures);
     size_t texel_bytes = 0;
     for (int i = 0; i < d->n_textures; i++) {
@@ -552,28 +717,17 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     for (int i = 0; i < d->n_primitives; i++) {
         const rt_primitive& p = d->primitives[i];
         DevPrimX& x = px[i];
-        x.root = RT_REF_END, x.tex_w = x.tex_h = 0, x.tex_off = 0, x.cull_scale = 0;
+        x.tex_w = x.tex_h = 0, x.tex_off = 0, x.pad_ = 0;
         if (p.material.texture >= 0) {
             const rt_texture& t = d->textures[p.material.texture];
             x.tex_w = t.width, x.tex_h = t.height, x.tex_off = tex_off[p.material.texture];
         }
-        if (p.type == RT_PRIM_MESH) {
-            const rt_mesh& m = d->meshes[p.u.mesh.mesh];
-            x.root = m.root;
-            double sc = 0;
-            if (m.root != RT_REF_END && !(m.root & RT_REF_LEAF)) {
-                const rt_bvh_node& n = d->nodes[m.root];
-                for (int k = 0; k < 3; k++) sc = std::fmax(sc, std::fmax(std::fabs(n.bmin[k]), std::fabs(n.bmax[k])));
-            } else if (m.root != RT_REF_END) {
-                const rt_bvh_leaf& lf = d->leaves[m.root & ~RT_REF_LEAF];
-                const double c[9] = {lf.O1.x, lf.O1.y, lf.O1.z, lf.O2.x, lf.O2.y, lf.O2.z, lf.O3.x, lf.O3.y, lf.O3.z};
-                for (double v : c) sc = std::fmax(sc, std::fabs(v));
-            }
-            x.cull_scale = 3.0 * sc;
-        }
+        build_geom(d, p, geom[i], segs);
     }
     size_t off_l = 0;
-    size_t off_p = align_up(off_l + sizeof(rt_light) * d->n_lights, 256);
+    size_t off_g = align_up(off_l + sizeof(rt_light) * d->n_lights, 256);
+    size_t off_s = align_up(off_g + sizeof(DevGeom) * d->n_primitives, 256);
+    size_t off_p = align_up(off_s + sizeof(DevGeom) * segs.size(), 256);
     size_t off_x = align_up(off_p + sizeof(rt_primitive) * d->n_primitives, 256);
     size_t off_n = align_up(off_x + sizeof(DevPrimX) * d->n_primitives, 256);
     size_t off_f = align_up(off_n + sizeof(rt_bvh_node) * (size_t)d->n_nodes, 256);
@@ -581,6 +735,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->slab_bytes = align_up(off_t + texel_bytes, 256) + 256;
     std::vector<uint8_t> host(s->slab_bytes, 0);
     if (d->n_lights) std::memcpy(&host[off_l], d->lights, sizeof(rt_light) * d->n_lights);
+    if (d->n_primitives) std::memcpy(&host[off_g], geom.data(), sizeof(DevGeom) * d->n_primitives);
+    if (!segs.empty()) std::memcpy(&host[off_s], segs.data(), sizeof(DevGeom) * segs.size());
     if (d->n_primitives) std::memcpy(&host[off_p], d->primitives, sizeof(rt_primitive) * d->n_primitives);
     if (d->n_primitives) std::memcpy(&host[off_x], px.data(), sizeof(DevPrimX) * d->n_primitives);
     if (d->n_nodes) std::memcpy(&host[off_n], d->nodes, sizeof(rt_bvh_node) * (size_t)d->n_nodes);
@@ -602,6 +758,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.shade_n = (int)(16 * d->camera.shade_quality);
     v.n_lights = d->n_lights, v.n_prims = d->n_primitives;
     v.lights = (const rt_light*)(base + off_l);
+    v.geom = (const DevGeom*)(base + off_g);
+    v.segs = (const DevGeom*)(base + off_s);
     v.prims = (const rt_primitive*)(base + off_p);
     v.primx = (const DevPrimX*)(base + off_x);
     v.nodes = (const rt_bvh_node*)(base + off_n);
@@ -609,7 +767,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.texels = base + off_t;
 
     HIPCHK(hipMalloc(&s->queue, 256));
-    HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * CTR_COUNT));
+    HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * CTR_ALL));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
     hipDeviceProp_t prop;
@@ -665,7 +823,7 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     HIPCHK(hipMemcpyAsync(s->tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(s->prefix, prefix.data(), prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
-    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CTR_COUNT, g_stream));
+    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CTR_ALL, g_stream));
 
     RenderParams P;
     P.sc = s->dev;
@@ -690,9 +848,14 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s->ev1, g_stream));
-    unsigned long long c[CTR_COUNT];
+    unsigned long long c[CTR_ALL];
     HIPCHK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+#ifdef RT_UTIL_COUNTERS
+    std::fprintf(stderr, "[util] shadow lanes used %.1f%% (%llu of %llu slots), closest-hit lanes used %.1f%% (%llu of %llu slots)\n",
+                 100.0 * c[CTR_U_SHADOW_ITEMS] / (double)(c[CTR_U_SHADOW_SLOTS] ? c[CTR_U_SHADOW_SLOTS] : 1), c[CTR_U_SHADOW_ITEMS], c[CTR_U_SHADOW_SLOTS],
+                 100.0 * c[CTR_U_TRACE_ACTIVE] / (double)(c[CTR_U_TRACE_SLOTS] ? c[CTR_U_TRACE_SLOTS] : 1), c[CTR_U_TRACE_ACTIVE], c[CTR_U_TRACE_SLOTS]);
+#endif
     if (stats) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));

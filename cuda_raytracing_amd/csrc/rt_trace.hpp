@@ -8,24 +8,55 @@
 #define RT_TRACE_HPP
 #include "rt_math.hpp"
 
-// Per-primitive data the device needs beyond rt_primitive.
+// Wave-uniform tables (primitive geometry, lights) are read through the constant address space:
+// with a uniform index the compiler then fetches them with scalar loads into SGPRs, which keeps
+// the vector registers for per-lane ray state.
+#define RT_CONST __attribute__((address_space(4)))
+
+// Intersection data of one top-level primitive (or of one cylinder segment of a Bezier stack),
+// with everything that does not depend on the ray computed once on the host: the same IEEE
+// double operations the reference performs per ray (CR/Collision.cu), so the values are
+// bit-identical, just not recomputed billions of times.
+struct DevGeom {  // 192 bytes
+    int32_t type;
+    uint32_t aux0;  // mesh: BVH root ref; bezier: first segment in DevScene::segs
+    int32_t aux1;   // bezier: number of segments
+    int32_t pad_;
+    double f[22];
+};
+// field map of DevGeom::f
+enum {
+    SPH_O = 0, SPH_R2 = 3,
+    PLN_N = 0, PLN_NR = 3,                                              // unit normal, unit normal * R
+    SQR_O = 0, SQR_N = 3, SQR_DX = 6, SQR_DY = 9, SQR_LX = 12, SQR_LY = 13,
+    CYL_O1 = 0, CYL_O2 = 3, CYL_DN = 6, CYL_LEN = 9, CYL_R2 = 10, CYL_NTOP = 11, CYL_NBOT = 14,
+    TRI_V1 = 0, TRI_E1 = 3, TRI_E2 = 6, TRI_N = 9,
+    MSH_SCALE = 0,
+    BND_C = 17, BND_R = 20                                              // bounding ball (cylinder, bezier, segments)
+};
+
+// Per-primitive shading extras (indexed per lane at a hit).
 struct DevPrimX {
-    uint32_t root;      // mesh: ref of the BVH root (RT_REF_END if empty / not a mesh)
     int32_t tex_w, tex_h;
-    uint32_t tex_off;   // byte offset of the texture in the texel pool
-    double cull_scale;  // mesh: |coordinates| bound used to size the culling safety margin
+    uint32_t tex_off;  // byte offset of the texture in the texel pool
+    uint32_t pad_;
 };
 
 struct DevScene {
     d3 bg_top, bg_bottom, camO, camN, camDx, camDy;
     int32_t cam_w, cam_h, shade_n, n_lights, n_prims;
-    const rt_light* __restrict__ lights;
-    const rt_primitive* __restrict__ prims;
-    const DevPrimX* __restrict__ primx;
-    const rt_bvh_node* __restrict__ nodes;
-    const rt_bvh_leaf* __restrict__ leaves;
-    const uint8_t* __restrict__ texels;
+    const rt_light* lights;        // read as RT_CONST
+    const DevGeom* geom;           // read as RT_CONST, one per primitive
+    const DevGeom* segs;           // read as RT_CONST, Bezier cylinder segments
+    const rt_primitive* prims;     // materials + texture frames, per-lane lookups
+    const DevPrimX* primx;
+    const rt_bvh_node* nodes;
+    const rt_bvh_leaf* leaves;
+    const uint8_t* texels;
 };
+#define GEOM(sc) ((const DevGeom RT_CONST*)(sc).geom)
+#define SEGS(sc) ((const DevGeom RT_CONST*)(sc).segs)
+#define LIGHTS(sc) ((const rt_light RT_CONST*)(sc).lights)
 
 struct Hit {  // CR/Primitive.cuh:107-113
     d3 N, C;
@@ -37,18 +68,40 @@ struct Hit {  // CR/Primitive.cuh:107-113
 
 struct Counters {  // per-lane work counters, flushed once per wave
     uint32_t rays_secondary, rays_shadow, nodes, tris, shaded, texfetch;
+#ifdef RT_UTIL_COUNTERS
+    uint32_t u_shadow_slots, u_shadow_items, u_trace_slots, u_trace_active;
+#endif
 };
 
+DEV d3 G3(const DevGeom RT_CONST& g, int i) { return d3{g.f[i], g.f[i + 1], g.f[i + 2]}; }
+
+// Conservative pre-test: false only if the ray (unit direction V) certainly misses the ball, or
+// the ball lies wholly behind the origin, or (t_max given) wholly beyond t_max.  The ball is
+// inflated on the host, so "certainly" holds with rounding to spare; primitives that fail it
+// report "no hit" exactly as their full test would.
+DEV bool ball_may_hit(const DevGeom RT_CONST& g, d3 o, d3 V, double t_max) {
+    d3 P = o - G3(g, BND_C);
+    double r = g.f[BND_R];
+    double b = -dot(P, V), pp = dot(P, P), r2 = r * r;
+    double disc = b * b - pp + r2;
+    if (disc < 0) return false;
+    if (b < 0 && pp > r2) return false;
+    double far = b - t_max;
+    if (far > 0 && far * far > disc && pp > r2) return false;
+    return true;
+}
+
 // ---- analytic primitives -------------------------------------------------------------------
-// Each returns the hit distance or RT_BIG_DIST.  `full` = also produce C, N, front (closest-hit
-// rays); shadow rays only need the distance.
+// Each returns the hit distance or RT_BIG_DIST.  FULL = also produce C, N, front (closest-hit
+// rays); shadow rays only need the distance.  V is the unit ray direction, computed once per
+// ray by the caller (every reference intersector starts with V = normalize(direction)).
 
 // CR/Collision.cu:155-176, CR/primitive.cpp:109-138
 template <bool FULL>
-DEV double sphere_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
-    d3 V = unit(d), O = D3(p.u.sphere.O), P = o - O;
-    double b = -dot(P, V), R = p.u.sphere.R;
-    double det = b * b - dot(P, P) + R * R;
+DEV double sphere_hit(const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
+    d3 O = G3(g, SPH_O), P = o - O;
+    double b = -dot(P, V);
+    double det = b * b - dot(P, P) + g.f[SPH_R2];
     if (!(det > RT_EPS)) return RT_BIG_DIST;
     det = sqrt(det);
     double x1 = b - det, x2 = b + det;
@@ -66,11 +119,11 @@ DEV double sphere_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
 
 // CR/Collision.cu:177-196, CR/primitive.cpp:159-175
 template <bool FULL>
-DEV double plane_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
-    d3 V = unit(d), N = unit(D3(p.u.plane.N));
+DEV double plane_hit(const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
+    d3 N = G3(g, PLN_N);
     double den = dot(N, V);
     if (!(fabs(den) >= RT_EPS)) return RT_BIG_DIST;
-    double t = dot(N * p.u.plane.R - o, N) / den;
+    double t = dot(G3(g, PLN_NR) - o, N) / den;
     if (!(t >= RT_EPS)) return RT_BIG_DIST;
     if (FULL) {
         h.C = o + V * t;
@@ -82,17 +135,15 @@ DEV double plane_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
 
 // CR/Collision.cu:197-256, CR/primitive.cpp:192-227
 template <bool FULL>
-DEV double square_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
-    d3 V = unit(d), Dx = D3(p.u.square.Dx), Dy = D3(p.u.square.Dy), O = D3(p.u.square.O);
-    d3 N = unit(cross(Dx, Dy));
+DEV double square_hit(const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
+    d3 O = G3(g, SQR_O), N = G3(g, SQR_N);
     double den = dot(N, V);
     if (fabs(den) < RT_EPS) return RT_BIG_DIST;
     double t = dot(O - o, N) / den;
     if (t < RT_EPS) return RT_BIG_DIST;
     d3 P = o + V * t;
-    double lx = dot(Dx, Dx), ly = dot(Dy, Dy);
-    double x2 = fabs(dot(P - O, Dx)), y2 = fabs(dot(P - O, Dy));
-    if (x2 > lx || y2 > ly) return RT_BIG_DIST;
+    double x2 = fabs(dot(P - O, G3(g, SQR_DX))), y2 = fabs(dot(P - O, G3(g, SQR_DY)));
+    if (x2 > g.f[SQR_LX] || y2 > g.f[SQR_LY]) return RT_BIG_DIST;
     if (FULL) {
         h.front = den < 0;
         h.C = P;
@@ -104,14 +155,12 @@ DEV double square_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
 // CR/Collision.cu:3-107.  front = false marks a body hit, true a cap hit (the texture lookup
 // reuses it that way, CR/Primitive.cu:56).
 template <bool FULL>
-DEV double cylinder_hit(d3 O1, d3 O2, double R, d3 o, d3 d, Hit& h) {
-    d3 V = unit(d);
+DEV double cylinder_hit(const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
+    d3 O1 = G3(g, CYL_O1), O2 = G3(g, CYL_O2);
     {
-        d3 dd = O2 - O1, m = o - O1;
-        double r2 = R * R;
-        d3 dN = unit(dd);
+        d3 m = o - O1, dN = G3(g, CYL_DN);
         d3 mP = cross(m, dN), vP = cross(V, dN);
-        double a = dot(vP, vP), b = 2.0 * dot(vP, mP), c = dot(mP, mP) - r2;
+        double a = dot(vP, vP), b = 2.0 * dot(vP, mP), c = dot(mP, mP) - g.f[CYL_R2];
         double det = b * b - 4 * a * c;
         if (det >= 0) {
             det = sqrt(det);
@@ -121,7 +170,7 @@ DEV double cylinder_hit(d3 O1, d3 O2, double R, d3 o, d3 d, Hit& h) {
             if (t >= 0) {
                 d3 P = o + V * t;
                 double u = dot(P - O1, dN);
-                if (u >= 0 && u <= module(dd)) {
+                if (u >= 0 && u <= g.f[CYL_LEN]) {
                     if (FULL) {
                         h.C = P;
                         h.front = false;
@@ -134,14 +183,14 @@ DEV double cylinder_hit(d3 O1, d3 O2, double R, d3 o, d3 d, Hit& h) {
     }
 #pragma unroll
     for (int cap = 0; cap < 2; cap++) {  // cap at O2 first, then cap at O1
-        d3 N = cap == 0 ? unit(O1 - O2) : unit(O2 - O1);
+        d3 N = cap == 0 ? G3(g, CYL_NTOP) : G3(g, CYL_NBOT);
         d3 Q0 = cap == 0 ? O2 : O1;
         double den = dot(N, V);
         if (fabs(den) >= RT_EPS) {
             double t = dot(Q0 - o, N) / den;
             if (t >= RT_EPS) {
                 d3 P = o + V * t, Q = P - Q0;
-                if (dot(Q, Q) <= R * R) {
+                if (dot(Q, Q) <= g.f[CYL_R2]) {
                     if (FULL) {
                         h.C = P;
                         h.front = true;
@@ -158,23 +207,13 @@ DEV double cylinder_hit(d3 O1, d3 O2, double R, d3 o, d3 d, Hit& h) {
 // CR/Collision_Bezier.cu:200-240: the profile as a stack of cylinders, including the way
 // `closest` trails one accepted hit behind.
 template <bool FULL>
-DEV double bezier_stacked_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
+DEV double bezier_stacked_hit(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 V, double t_max, Hit& h) {
     double closest = 1e10, cur = RT_BIG_DIST;
-    d3 O1 = D3(p.u.bezier.O1), axis = unit(D3(p.u.bezier.O2) - O1);
-    for (int i = 0; i < p.u.bezier.degree; i++) {
-        d3 p1, p2;
-        double R;
-        if (i == 0) {
-            p1 = O1;
-            p2 = O1 + axis * p.u.bezier.Z[0];
-            R = p.u.bezier.R_c;
-        } else {
-            p1 = O1 + axis * p.u.bezier.Z[i - 1];
-            p2 = O1 + axis * p.u.bezier.Z[i];
-            R = p.u.bezier.R[i];
-        }
+    for (int i = 0; i < g.aux1; i++) {
+        const DevGeom RT_CONST& seg = SEGS(sc)[g.aux0 + i];
+        if (!ball_may_hit(seg, o, V, t_max)) continue;
         Hit tmp;
-        double t = cylinder_hit<FULL>(p1, p2, R, o, d, tmp);
+        double t = cylinder_hit<FULL>(seg, o, V, tmp);
         if (t < RT_BIG_DIST && t < closest) {
             closest = cur;
             cur = t;
@@ -184,10 +223,11 @@ DEV double bezier_stacked_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
     return cur;
 }
 
-// CR/Collision.cu:110-149,267-282 (standalone triangle; the normal is not flipped)
+// CR/Collision.cu:110-149,267-282 (standalone triangle; the normal is not flipped; d is the
+// direction as given or normalised, see RT_F_MESH_RAW_DIR)
 template <bool FULL>
-DEV double triangle_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
-    d3 V1 = D3(p.u.triangle.O1), e1 = D3(p.u.triangle.O2) - V1, e2 = D3(p.u.triangle.O3) - V1;
+DEV double triangle_hit(const DevGeom RT_CONST& g, d3 o, d3 d, Hit& h) {
+    d3 V1 = G3(g, TRI_V1), e1 = G3(g, TRI_E1), e2 = G3(g, TRI_E2);
     d3 hh = cross(d, e2);
     double a = dot(e1, hh);
     if (fabs(a) < RT_EPS) return RT_BIG_DIST;
@@ -202,7 +242,7 @@ DEV double triangle_hit(const rt_primitive& p, d3 o, d3 d, Hit& h) {
     if (!(t > RT_EPS)) return RT_BIG_DIST;
     if (FULL) {
         h.C = o + d * t;
-        h.N = unit(cross(e1, e2));
+        h.N = G3(g, TRI_N);
         h.front = dot(d, h.N) < 0;
     }
     return t;
@@ -324,24 +364,29 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
     best.prim = -1, best.leaf = -1, best.dist = RT_BIG_DIST, best.front = false;
     best.N = D3(0, 0, 0), best.C = D3(0, 0, 0);
     const bool later_wins = (flags & RT_F_TIE_LATER_WINS) != 0;
+    const d3 V = unit(d);                                   // what every intersector normalises to
+    const d3 dm = (flags & RT_F_MESH_RAW_DIR) ? d : V;      // triangle / mesh direction
     for (int i = 0; i < sc.n_prims; i++) {
-        const rt_primitive& p = sc.prims[i];
+        const DevGeom RT_CONST& g = GEOM(sc)[i];
         Hit tmp;
         tmp.leaf = -1;
         double t = RT_BIG_DIST;
-        switch (p.type) {
-            case RT_PRIM_SPHERE: t = sphere_hit<true>(p, o, d, tmp); break;
-            case RT_PRIM_PLANE: t = plane_hit<true>(p, o, d, tmp); break;
-            case RT_PRIM_SQUARE: t = square_hit<true>(p, o, d, tmp); break;
-            case RT_PRIM_CYLINDER: t = cylinder_hit<true>(D3(p.u.cylinder.O1), D3(p.u.cylinder.O2), p.u.cylinder.R, o, d, tmp); break;
-            case RT_PRIM_BEZIER: t = bezier_stacked_hit<true>(p, o, d, tmp); break;
-            case RT_PRIM_TRIANGLE: t = triangle_hit<true>(p, o, (flags & RT_F_MESH_RAW_DIR) ? d : unit(d), tmp); break;
+        // a hit can only replace the best one if it is closer (or within 1e-6 under later-wins)
+        const double lim = later_wins ? best.dist + RT_EPS : best.dist;
+        switch (g.type) {
+            case RT_PRIM_SPHERE: t = sphere_hit<true>(g, o, V, tmp); break;
+            case RT_PRIM_PLANE: t = plane_hit<true>(g, o, V, tmp); break;
+            case RT_PRIM_SQUARE: t = square_hit<true>(g, o, V, tmp); break;
+            case RT_PRIM_CYLINDER:
+                if (ball_may_hit(g, o, V, lim)) t = cylinder_hit<true>(g, o, V, tmp);
+                break;
+            case RT_PRIM_BEZIER:
+                if (ball_may_hit(g, o, V, RT_BIG_DIST)) t = bezier_stacked_hit<true>(sc, g, o, V, RT_BIG_DIST, tmp);
+                break;
+            case RT_PRIM_TRIANGLE: t = triangle_hit<true>(g, o, dm, tmp); break;
             case RT_PRIM_MESH: {
-                d3 dm = (flags & RT_F_MESH_RAW_DIR) ? d : unit(d);
-                // only hits that can still win matter: t < best (or < best + 1e-6 under the later-wins rule)
-                double lim = later_wins ? best.dist + RT_EPS : best.dist;
-                MeshResult r = mesh_walk<STRICT, false, LOG>(sc, sc.primx[i].root, o, dm, lim, sc.primx[i].cull_scale, ctr, log,
-                                                             log_cap, log_n, (uint32_t)p.u.mesh.mesh << 24);
+                MeshResult r = mesh_walk<STRICT, false, LOG>(sc, g.aux0, o, dm, lim, g.f[MSH_SCALE], ctr, log, log_cap, log_n,
+                                                             (uint32_t)g.aux1 << 24);
                 t = r.t;
                 if (t < RT_BIG_DIST) mesh_fill_hit(sc, r.leaf, o, dm, t, tmp);
                 break;
@@ -360,32 +405,102 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
     return best;
 }
 
+// ---- which primitives can shadow a point from a lamp at all ------------------------------------
+// For a shaded point A and a lamp (centre Lc, every sample within Rl of Lc), every shadow ray of
+// that lamp runs inside the capsule of radius Rl around the segment A..Lc.  A primitive whose
+// bounding ball stays clear of that capsule (or a plane that has A and the whole lamp strictly on
+// one side) reports "no occlusion" for every sample, so its test can be skipped for all of them;
+// bit j of the result is cleared for such primitives.  Radii are inflated so that "clear" holds
+// with rounding to spare.  Under RT_F_MESH_RAW_DIR a mesh / triangle hit counts up to ray parameter
+// |L - A| (CR/Collision_Mesh.cu:19-63 does not normalise the direction), i.e. far beyond the lamp,
+// so their capsule is stretched accordingly.
+DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L) {
+    if (sc.n_prims > 64) return ~0ull;
+    double Rl = 0.0;
+    if (L.type == RT_LIGHT_SPHERE) Rl = fabs(L.R);
+    else if (L.type == RT_LIGHT_SQUARE) Rl = module(d3{L.Dx.x, L.Dx.y, L.Dx.z}) + module(d3{L.Dy.x, L.Dy.y, L.Dy.z});
+    Rl = Rl * (1.0 + 1e-6) + 1e-9;
+    const d3 Lc = d3{L.O.x, L.O.y, L.O.z}, D = Lc - A;
+    const double L2 = dot(D, D);
+    if (!(L2 > 1e-200) || !(L2 < 1e200) || !(Rl < 1e100)) return ~0ull;
+    const double inv = 1.0 / L2, len = sqrt(L2);
+    const double s_raw = (len + Rl) * (1.0 + 1e-6), r_raw = Rl * s_raw + 1e-9;  // stretched capsule (raw-direction meshes)
+    const bool raw = (flags & RT_F_MESH_RAW_DIR) != 0;
+    unsigned long long m = 0;
+    for (int j = 0; j < sc.n_prims; j++) {
+        const DevGeom RT_CONST& g = GEOM(sc)[j];
+        bool may = true;
+        if (g.type == RT_PRIM_PLANE) {
+            const d3 N = G3(g, PLN_N), Q = G3(g, PLN_NR);
+            const double sa = dot(A - Q, N), sl = dot(Lc - Q, N);
+            const double tol = 1e-7 * (1.0 + fabs(sa) + fabs(sl));
+            if ((sa > tol && sl > Rl + tol) || (sa < -tol && sl < -(Rl + tol))) may = false;
+        } else {
+            const bool stretched = raw && (g.type == RT_PRIM_MESH || g.type == RT_PRIM_TRIANGLE);
+            const double smax = stretched ? s_raw : 1.0, rc = stretched ? r_raw : Rl;
+            const d3 w = G3(g, BND_C) - A;
+            double sp = dot(w, D) * inv;
+            sp = fmin(fmax(sp, 0.0), smax);
+            const d3 e = w - D * sp;
+            const double rr = g.f[BND_R] + rc;
+            if (dot(e, e) > rr * rr * (1.0 + 1e-9)) may = false;
+        }
+        if (may) m |= 1ull << j;
+    }
+    return m;
+}
+
 // ---- one shadow ray: CR/Shade.cu:36-46,64-75,94-105, CR/Light.cpp:35-40,67-78 ----------------
 // true = nothing between C and target.  A primitive occludes if dist - its_hit_distance > 1e-6.
 template <bool STRICT>
-DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, Counters& ctr) {
-    d3 V = target - C;
-    double dist = module(V);
+DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
+                      Counters& ctr) {
+    const d3 Vv = target - C;
+    const double dist = module(Vv);
+    const d3 V = Vv / dist;                                  // = normalize(Vv)
+    const d3 dm = (flags & RT_F_MESH_RAW_DIR) ? Vv : V;
     uint32_t dummy_n = 0;
     const bool self_skip = (flags & RT_F_SHADOW_SELF_SKIP) != 0;
+#ifdef RT_ABLATE_ALL_SHADOW  // timing experiments only: results are wrong in RT_ABLATE_* builds
+    return dist > 0;
+#endif
     for (int j = 0; j < sc.n_prims; j++) {
+        if (!STRICT) {
+            // primitives that cannot lie between any lane's shaded point and its lamp are skipped by the whole wave
+            const bool mine = j >= 64 || ((cand >> j) & 1ull);
+            if (__ballot(mine) == 0ull) continue;
+            if (!mine) continue;
+        }
         if (self_skip && j == crashed) continue;
         if (j == light_prim) continue;
-        const rt_primitive& p = sc.prims[j];
+        const DevGeom RT_CONST& g = GEOM(sc)[j];
         Hit tmp;
         double t = RT_BIG_DIST;
-        switch (p.type) {
-            case RT_PRIM_SPHERE: t = sphere_hit<false>(p, C, V, tmp); break;
-            case RT_PRIM_PLANE: t = plane_hit<false>(p, C, V, tmp); break;
-            case RT_PRIM_SQUARE: t = square_hit<false>(p, C, V, tmp); break;
-            case RT_PRIM_CYLINDER: t = cylinder_hit<false>(D3(p.u.cylinder.O1), D3(p.u.cylinder.O2), p.u.cylinder.R, C, V, tmp); break;
-            case RT_PRIM_BEZIER: t = bezier_stacked_hit<false>(p, C, V, tmp); break;
-            case RT_PRIM_TRIANGLE: t = triangle_hit<false>(p, C, (flags & RT_F_MESH_RAW_DIR) ? V : unit(V), tmp); break;
-            case RT_PRIM_MESH: {
-                d3 dm = (flags & RT_F_MESH_RAW_DIR) ? V : unit(V);
-                t = mesh_walk<STRICT, true, false>(sc, sc.primx[j].root, C, dm, dist, sc.primx[j].cull_scale, ctr, nullptr, 0, dummy_n, 0).t;
+#ifdef RT_ABLATE_MESH
+        if (g.type == RT_PRIM_MESH) continue;
+#endif
+#ifdef RT_ABLATE_CYL
+        if (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER) continue;
+#endif
+#ifdef RT_ABLATE_SPHERE
+        if (g.type == RT_PRIM_SPHERE || g.type == RT_PRIM_PLANE) continue;
+#endif
+        switch (g.type) {
+            case RT_PRIM_SPHERE: t = sphere_hit<false>(g, C, V, tmp); break;
+            case RT_PRIM_PLANE: t = plane_hit<false>(g, C, V, tmp); break;
+            case RT_PRIM_SQUARE: t = square_hit<false>(g, C, V, tmp); break;
+            case RT_PRIM_CYLINDER:
+                if (ball_may_hit(g, C, V, dist)) t = cylinder_hit<false>(g, C, V, tmp);
                 break;
-            }
+            case RT_PRIM_BEZIER:
+                // the stack's `closest` bookkeeping can return a far segment's distance, so segments
+                // are not pruned by distance here, only by direction
+                if (ball_may_hit(g, C, V, RT_BIG_DIST)) t = bezier_stacked_hit<false>(sc, g, C, V, RT_BIG_DIST, tmp);
+                break;
+            case RT_PRIM_TRIANGLE: t = triangle_hit<false>(g, C, dm, tmp); break;
+            case RT_PRIM_MESH:
+                t = mesh_walk<STRICT, true, false>(sc, g.aux0, C, dm, dist, g.f[MSH_SCALE], ctr, nullptr, 0, dummy_n, 0).t;
+                break;
             default: break;
         }
         if (dist - t > RT_EPS) return false;
@@ -489,17 +604,17 @@ DEV d3 texture_color(const DevScene& sc, uint32_t flags, const Hit& c, Counters&
 }
 
 // Point on a light for sample draws (a, b): CR/Shade.cu:3-21
-DEV d3 light_sample(const rt_light& L, float fa, float fb) {
+DEV d3 light_sample(const rt_light RT_CONST& L, float fa, float fb) {
     if (L.type == RT_LIGHT_SQUARE) {
         double a = (double)(2 * fa) - 1.0, b = (double)(2 * fb) - 1.0;
-        return D3(L.O) + D3(L.Dx) * a + D3(L.Dy) * b;
+        return d3{L.O.x, L.O.y, L.O.z} + d3{L.Dx.x, L.Dx.y, L.Dx.z} * a + d3{L.Dy.x, L.Dy.y, L.Dy.z} * b;
     }
     double z = 2.0 * fa - 1.0;
     double th = fb * 2.0 * M_PI;
     double r = sqrt(1.0 - z * z), sn, cs;
     det_sincos(th, sn, cs);
     double x = r * cs, y = r * sn;
-    return D3(L.O) + D3(L.R * x, L.R * y, L.R * z);
+    return d3{L.O.x, L.O.y, L.O.z} + D3(L.R * x, L.R * y, L.R * z);
 }
 
 #endif
