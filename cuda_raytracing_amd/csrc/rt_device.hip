@@ -28,6 +28,7 @@
 #include "rt_trace.hpp"
 
 static_assert(sizeof(rt_bvh_node) == 64 && sizeof(rt_bvh_leaf) == 96, "BVH record sizes are part of the ABI");
+static_assert(sizeof(DevNode2) == 128 && sizeof(DevGeom) == 192, "device record sizes");
 static_assert(sizeof(rt_primitive) == 408 && sizeof(rt_light) == 112 && sizeof(rt_scene_desc) == 256 && sizeof(rt_settings) == 40 &&
                   sizeof(rt_stats) == 80,
               "record sizes are part of the ABI (the Python binding mirrors them)");
@@ -84,7 +85,7 @@ DEV uint32_t to_u8(double c) {
 // CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
 template <bool STRICT>
 DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need, const Hit& h, uint32_t& draw, uint32_t pixel,
-                      uint32_t smp, Counters& ctr) {
+                      uint32_t smp, Counters& ctr, uint32_t* stk) {
     const DevScene& sc = P.sc;
     const int lane = lane_id();
     d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
@@ -149,7 +150,7 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
                     frand_pair(P.k0, P.k1, opix, osmp, odraw + off + 2u * (uint32_t)si, fa, fb);
                     target = light_sample(L, fa, fb);
                 }
-                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, ctr);
+                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, ctr, stk);
             }
             const unsigned long long cm = __ballot(clear);
             if (work) {
@@ -191,7 +192,8 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
 enum { ST_REFL = 1, ST_REFR = 2, ST_PENDING_REFR = 4, ST_FRONT = 8 };
 
 template <bool STRICT>
-DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t smp, d3 o, d3 d, uint32_t draw, Counters& ctr) {
+DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t smp, d3 o, d3 d, uint32_t draw, Counters& ctr,
+                   uint32_t* stk) {
     const DevScene& sc = P.sc;
     // frame k = the hit at depth k+1 that is waiting for a child ray to return
     double f_acc[RT_MAX_DEPTH][3], f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3], f_dist[RT_MAX_DEPTH];
@@ -213,7 +215,7 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
 #endif
         if (tracing && sp + 1 <= RT_MAX_DEPTH) {
             if (sp > 0) ctr.rays_secondary++;
-            h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log);
+            h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log, stk);
             if (h.prim < 0) {
                 d3 c = unit(d);
                 double t = 0.5 * (((P.flags & RT_F_SKY_Y) ? c.y : c.z) + 1.0);
@@ -231,7 +233,7 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
         }
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);
-        if (mask != 0ull) local = diffusion_coop<STRICT>(P, mask, need_shade, h, draw, pixel, smp, ctr);
+        if (mask != 0ull) local = diffusion_coop<STRICT>(P, mask, need_shade, h, draw, pixel, smp, ctr, stk);
 
         if (tracing) {
             bool have_result = !surface;
@@ -333,6 +335,9 @@ template <bool STRICT>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
     const int lane = lane_id();
     const DevScene& sc = P.sc;
+    // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
+    __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
+    uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
     Counters ctr;
     ctr.rays_secondary = ctr.rays_shadow = ctr.nodes = ctr.tris = ctr.shaded = ctr.texfetch = 0;
 #ifdef RT_UTIL_COUNTERS
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
                     d = unit(focal - o);
                 }
             }
-            d3 col = trace_paths<STRICT>(P, active, pixel, (uint32_t)s, o, d, draw, ctr);
+            d3 col = trace_paths<STRICT>(P, active, pixel, (uint32_t)s, o, d, draw, ctr, stk);
             // add this pass's samples in sample order
             const int n_here = (spp - pass * 64) < group ? (spp - pass * 64) : group;
             const int first = slot * group;
@@ -451,8 +456,8 @@ __global__ __launch_bounds__(256) void probe_kernel(ProbeParams Q) {
     Counters ctr;
     uint32_t n = 0;
     uint32_t* log = Q.visit_log ? Q.visit_log + (size_t)i * Q.visit_cap : nullptr;
-    Hit h = log ? scene_closest<true, true>(Q.sc, Q.flags, Q.sc.camO, d, ctr, log, (uint32_t)Q.visit_cap, n)
-                : scene_closest<true, false>(Q.sc, Q.flags, Q.sc.camO, d, ctr, nullptr, 0, n);
+    Hit h = log ? scene_closest<true, true>(Q.sc, Q.flags, Q.sc.camO, d, ctr, log, (uint32_t)Q.visit_cap, n, nullptr)
+                : scene_closest<true, false>(Q.sc, Q.flags, Q.sc.camO, d, ctr, nullptr, 0, n, nullptr);
     Q.hit_prim[i] = h.prim;
     Q.hit_t[i] = h.dist;
     Q.hit_leaf[i] = h.leaf;
@@ -541,7 +546,7 @@ static int validate_desc(const rt_scene_desc* d) {
     }
     for (uint32_t i = 0; i < d->n_nodes; i++) {
         const rt_bvh_node& n = d->nodes[i];
-        if (!link_ok(d, n.preorder, n.left, false) || !link_ok(d, n.preorder, n.skip, true)) return rt_fail(RT_ERR_INVALID, "BVH node link out of range or not forward");
+        if (!link_ok(d, n.preorder, n.left, false) || !link_ok(d, n.preorder, n.right, false) || !link_ok(d, n.preorder, n.skip, true)) return rt_fail(RT_ERR_INVALID, "BVH node link out of range or not forward");
     }
     for (uint32_t i = 0; i < d->n_leaves; i++)
         if (!link_ok(d, d->leaves[i].preorder, d->leaves[i].skip, true)) return rt_fail(RT_ERR_INVALID, "BVH leaf link out of range or not forward");
@@ -590,6 +595,48 @@ static void cylinder_geom(DevGeom& g, hostmath::h3 O1, hostmath::h3 O2, double R
     put(g, CYL_NBOT, hunit(O2 - O1));
     double half = 0.5 * hmodule(dd);
     set_ball(g, (O1 + O2) * 0.5, std::sqrt(half * half + R * R));
+}
+
+// depth of the subtree under `root` (links were validated to run forward, so this terminates)
+static uint32_t measured_depth(const rt_scene_desc* d, uint32_t root) {
+    if (root == RT_REF_END || (root & RT_REF_LEAF)) return 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st{{root, 0u}};
+    uint32_t best = 0;
+    while (!st.empty()) {
+        auto [ref, dep] = st.back();
+        st.pop_back();
+        best = std::max(best, dep);
+        if (ref == RT_REF_END || (ref & RT_REF_LEAF)) continue;
+        st.push_back({d->nodes[ref].left, dep + 1});
+        st.push_back({d->nodes[ref].right, dep + 1});
+    }
+    return best;
+}
+
+// paired-box copy of the interior nodes (DevNode2): child boxes from the children themselves
+static void build_nodes2(const rt_scene_desc* d, std::vector<DevNode2>& out) {
+    out.assign(d->n_nodes, DevNode2{});
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        const rt_bvh_node& n = d->nodes[i];
+        const uint32_t ch[2] = {n.left, n.right};
+        for (int c = 0; c < 2; c++) {
+            out[i].child[c] = ch[c];
+            if (ch[c] == RT_REF_END) {  // cannot happen in a tree built by the loader; make the box unhittable
+                for (int k = 0; k < 3; k++) out[i].lo[c][k] = 1e300, out[i].hi[c][k] = -1e300;
+            } else if (ch[c] & RT_REF_LEAF) {
+                const rt_bvh_leaf& lf = d->leaves[ch[c] & ~RT_REF_LEAF];
+                const double v[3][3] = {{lf.O1.x, lf.O1.y, lf.O1.z}, {lf.O2.x, lf.O2.y, lf.O2.z}, {lf.O3.x, lf.O3.y, lf.O3.z}};
+                for (int k = 0; k < 3; k++) {
+                    double lo = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k])), hi = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+                    double pad = 1e-9 * (1.0 + std::fabs(lo) + std::fabs(hi)) + 1e-7 * (hi - lo);
+                    out[i].lo[c][k] = lo - pad, out[i].hi[c][k] = hi + pad;
+                }
+            } else {
+                const rt_bvh_node& cn = d->nodes[ch[c]];
+                for (int k = 0; k < 3; k++) out[i].lo[c][k] = cn.bmin[k], out[i].hi[c][k] = cn.bmax[k];
+            }
+        }
+    }
 }
 
 static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g, std::vector<DevGeom>& segs) {
@@ -667,6 +714,8 @@ static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g
                 hi = h3{std::fmax(c[0], std::fmax(c[3], c[6])), std::fmax(c[1], std::fmax(c[4], c[7])), std::fmax(c[2], std::fmax(c[5], c[8]))};
             }
             g.f[MSH_SCALE] = 3.0 * sc;
+            put(g, MSH_BMIN, lo), put(g, MSH_BMAX, hi);
+            g.aux2 = (measured_depth(d, m.root) + 2 <= RT_STACK) ? 1 : 0;
             set_ball(g, (lo + hi) * 0.5, 0.5 * hmodule(hi - lo));  // empty mesh: a point ball, never reached
             break;
         }
@@ -708,6 +757,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<DevPrimX> px((size_t)d->n_primitives);
     std::vector<DevGeom> geom((size_t)d->n_primitives), segs;
     std::vector<uint32_t> tex_off((size_t)d->n_textures);
+    std::vector<DevNode2> nodes2;
+    build_nodes2(d, nodes2);
     size_t texel_bytes = 0;
     for (int i = 0; i < d->n_textures; i++) {
         tex_off[i] = (uint32_t)texel_bytes;
@@ -730,7 +781,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     size_t off_p = align_up(off_s + sizeof(DevGeom) * segs.size(), 256);
     size_t off_x = align_up(off_p + sizeof(rt_primitive) * d->n_primitives, 256);
     size_t off_n = align_up(off_x + sizeof(DevPrimX) * d->n_primitives, 256);
-    size_t off_f = align_up(off_n + sizeof(rt_bvh_node) * (size_t)d->n_nodes, 256);
+    size_t off_n2 = align_up(off_n + sizeof(rt_bvh_node) * (size_t)d->n_nodes, 256);
+    size_t off_f = align_up(off_n2 + sizeof(DevNode2) * (size_t)d->n_nodes, 256);
     size_t off_t = align_up(off_f + sizeof(rt_bvh_leaf) * (size_t)d->n_leaves, 256);
     s->slab_bytes = align_up(off_t + texel_bytes, 256) + 256;
     std::vector<uint8_t> host(s->slab_bytes, 0);
@@ -740,6 +792,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (d->n_primitives) std::memcpy(&host[off_p], d->primitives, sizeof(rt_primitive) * d->n_primitives);
     if (d->n_primitives) std::memcpy(&host[off_x], px.data(), sizeof(DevPrimX) * d->n_primitives);
     if (d->n_nodes) std::memcpy(&host[off_n], d->nodes, sizeof(rt_bvh_node) * (size_t)d->n_nodes);
+    if (d->n_nodes) std::memcpy(&host[off_n2], nodes2.data(), sizeof(DevNode2) * (size_t)d->n_nodes);
     if (d->n_leaves) std::memcpy(&host[off_f], d->leaves, sizeof(rt_bvh_leaf) * (size_t)d->n_leaves);
     for (int i = 0; i < d->n_textures; i++)
         std::memcpy(&host[off_t + tex_off[i]], d->textures[i].rgb, (size_t)d->textures[i].width * d->textures[i].height * 3);
@@ -763,6 +816,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.prims = (const rt_primitive*)(base + off_p);
     v.primx = (const DevPrimX*)(base + off_x);
     v.nodes = (const rt_bvh_node*)(base + off_n);
+    v.nodes2 = (const DevNode2*)(base + off_n2);
     v.leaves = (const rt_bvh_leaf*)(base + off_f);
     v.texels = base + off_t;
 

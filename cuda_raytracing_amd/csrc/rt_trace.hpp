@@ -20,8 +20,8 @@
 struct DevGeom {  // 192 bytes
     int32_t type;
     uint32_t aux0;  // mesh: BVH root ref; bezier: first segment in DevScene::segs
-    int32_t aux1;   // bezier: number of segments
-    int32_t pad_;
+    int32_t aux1;   // bezier: number of segments; mesh: mesh index
+    int32_t aux2;   // mesh: 1 if the paired-box tree + LDS stack walk may be used (depth fits the stack)
     double f[22];
 };
 // field map of DevGeom::f
@@ -31,8 +31,20 @@ enum {
     SQR_O = 0, SQR_N = 3, SQR_DX = 6, SQR_DY = 9, SQR_LX = 12, SQR_LY = 13,
     CYL_O1 = 0, CYL_O2 = 3, CYL_DN = 6, CYL_LEN = 9, CYL_R2 = 10, CYL_NTOP = 11, CYL_NBOT = 14,
     TRI_V1 = 0, TRI_E1 = 3, TRI_E2 = 6, TRI_N = 9,
-    MSH_SCALE = 0,
+    MSH_SCALE = 0, MSH_BMIN = 1, MSH_BMAX = 4,                          // culling scale, root box (= the root node's box)
     BND_C = 17, BND_R = 20                                              // bounding ball (cylinder, bezier, segments)
+};
+
+// Interior BVH node for the pruned walk: the boxes of BOTH children next to their refs, so one
+// fetch decides both descents and the nearer child can be entered first.  Same tree, same boxes
+// as rt_bvh_node (interior children carry the exact box the reference tests, CR/Collision_Mesh.cu:75);
+// a leaf child carries its triangle's bounds, slightly inflated, as a pre-test the reference does not
+// have - it can only discard triangles the ray misses.
+#define RT_STACK 24  // per-lane traversal stack entries (LDS); meshes deeper than RT_STACK - 2 use the stackless walk
+struct DevNode2 {    // 128 bytes
+    double lo[2][3], hi[2][3];
+    uint32_t child[2];
+    uint32_t pad_[6];
 };
 
 // Per-primitive shading extras (indexed per lane at a hit).
@@ -51,6 +63,7 @@ struct DevScene {
     const rt_primitive* prims;     // materials + texture frames, per-lane lookups
     const DevPrimX* primx;
     const rt_bvh_node* nodes;
+    const DevNode2* nodes2;        // same indices as `nodes`
     const rt_bvh_leaf* leaves;
     const uint8_t* texels;
 };
@@ -345,6 +358,103 @@ DEV MeshResult mesh_walk(const DevScene& sc, uint32_t root, d3 o, d3 d, double t
     return res;
 }
 
+// Pruned walk over the paired-box tree with a per-lane stack in LDS (`stk` points at this lane's
+// column; entry k lives at stk[k * 64]).  Children are entered nearest first, the other one is
+// pushed.  It tests a subset of the triangles the reference-order walk tests - never one more,
+// and never drops one that could be the answer:
+//   * an interior child is entered only if the reference's own slab test passes (same arithmetic),
+//     it is not wholly behind the origin and not wholly beyond t_limit (both relaxed by `margin`);
+//   * a leaf child is dropped only if the ray misses its inflated bounds or they lie beyond t_limit;
+//   * ties go to the smaller pre-order index, which is the leaf the reference meets first.
+template <bool ANYHIT>
+DEV MeshResult mesh_walk_fast(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk) {
+    MeshResult res{RT_BIG_DIST, RT_REF_END};
+    uint32_t res_pre = 0xFFFFFFFFu;
+    const double t_exact = t_limit;
+    const d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    double m = 0.0;
+    if (fabs(inv.x) < 1e300) m = fmax(m, fabs(inv.x));
+    if (fabs(inv.y) < 1e300) m = fmax(m, fabs(inv.y));
+    if (fabs(inv.z) < 1e300) m = fmax(m, fabs(inv.z));
+    const double margin = 1e-13 * (g.f[MSH_SCALE] + fabs(o.x) + fabs(o.y) + fabs(o.z)) * m;
+    t_limit = t_limit + margin + 1e-9 * fabs(t_limit);
+    uint32_t ref = g.aux0;
+    if (ref == RT_REF_END) return res;
+    if (!(ref & RT_REF_LEAF)) {  // root box (CR/Renderer_CUDA.cpp:234-235: the vertex bounds)
+        ctr.nodes++;
+        double t0x = (g.f[MSH_BMIN] - o.x) * inv.x, t1x = (g.f[MSH_BMAX] - o.x) * inv.x;
+        double t0y = (g.f[MSH_BMIN + 1] - o.y) * inv.y, t1y = (g.f[MSH_BMAX + 1] - o.y) * inv.y;
+        double t0z = (g.f[MSH_BMIN + 2] - o.z) * inv.z, t1z = (g.f[MSH_BMAX + 2] - o.z) * inv.z;
+        double tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
+        double tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
+        if (!(tn <= tf) || tn > t_limit || tf < -margin) return res;
+    }
+    int sp = 0;
+    for (;;) {
+        while (!(ref & RT_REF_LEAF)) {
+            const DevNode2& n = sc.nodes2[ref];
+            ctr.nodes++;
+            bool ok[2];
+            double tn[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                double t0x = (n.lo[c][0] - o.x) * inv.x, t1x = (n.hi[c][0] - o.x) * inv.x;
+                double t0y = (n.lo[c][1] - o.y) * inv.y, t1y = (n.hi[c][1] - o.y) * inv.y;
+                double t0z = (n.lo[c][2] - o.z) * inv.z, t1z = (n.hi[c][2] - o.z) * inv.z;
+                double a = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
+                double b = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
+                const bool leafc = (n.child[c] & RT_REF_LEAF) != 0;
+                bool e = leafc ? !(a > b + margin) : (a <= b);
+                ok[c] = e && !(a > t_limit) && !(b < -margin);
+                tn[c] = a;
+            }
+            if (ok[0] && ok[1]) {
+                const int near = tn[1] < tn[0] ? 1 : 0;
+                if (sp < RT_STACK) stk[sp * 64] = n.child[near ^ 1], sp++;
+                ref = n.child[near];
+            } else if (ok[0]) {
+                ref = n.child[0];
+            } else if (ok[1]) {
+                ref = n.child[1];
+            } else if (sp > 0) {
+                ref = stk[(--sp) * 64];
+            } else {
+                ref = RT_REF_END;
+            }
+        }
+        if (ref == RT_REF_END) break;
+        const rt_bvh_leaf& lf = sc.leaves[ref & ~RT_REF_LEAF];
+        ctr.tris++;
+        const uint32_t here = ref;
+        ref = sp > 0 ? stk[(--sp) * 64] : RT_REF_END;
+        d3 O1 = D3(lf.O1), e1 = D3(lf.O2) - O1, e2 = D3(lf.O3) - O1;
+        d3 p = cross(d, e2);
+        double det = dot(e1, p);
+        if (fabs(det) < RT_EPS) continue;
+        double idet = 1.0 / det;
+        d3 tv = o - O1;
+        double u = dot(tv, p) * idet;
+        if (u < 0.0 || u > 1.0) continue;
+        d3 q = cross(tv, e1);
+        double v = dot(d, q) * idet;
+        if (v < 0.0 || u + v > 1.0) continue;
+        double t0 = dot(e2, q) * idet;
+        if (t0 <= RT_EPS) continue;
+        if (t0 < res.t || (t0 == res.t && lf.preorder < res_pre)) {
+            res.t = t0;
+            res.leaf = here;
+            res_pre = lf.preorder;
+            if (ANYHIT) {
+                if (t_exact - t0 > RT_EPS) break;
+            } else {
+                double lim = t0 + margin + 1e-9 * fabs(t0);
+                if (lim < t_limit) t_limit = lim;
+            }
+        }
+    }
+    return res;
+}
+
 // CR/Collision_Mesh.cu:45-60: hit record of the winning leaf (normal as CR/primitive.cpp:457 stores it)
 DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double t0, Hit& h) {
     const rt_bvh_leaf& lf = sc.leaves[leafref & ~RT_REF_LEAF];
@@ -359,7 +469,7 @@ DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double 
 // ---- closest hit over the scene: CR/Scene.cu:3-21, CR/Scene.cpp:27-38 ---------------------
 template <bool STRICT, bool LOG>
 DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint32_t* log, uint32_t log_cap,
-                      uint32_t& log_n) {
+                      uint32_t& log_n, uint32_t* stk) {
     Hit best;
     best.prim = -1, best.leaf = -1, best.dist = RT_BIG_DIST, best.front = false;
     best.N = D3(0, 0, 0), best.C = D3(0, 0, 0);
@@ -385,8 +495,10 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
                 break;
             case RT_PRIM_TRIANGLE: t = triangle_hit<true>(g, o, dm, tmp); break;
             case RT_PRIM_MESH: {
-                MeshResult r = mesh_walk<STRICT, false, LOG>(sc, g.aux0, o, dm, lim, g.f[MSH_SCALE], ctr, log, log_cap, log_n,
-                                                             (uint32_t)g.aux1 << 24);
+                MeshResult r = (!STRICT && g.aux2 && stk)
+                                   ? mesh_walk_fast<false>(sc, g, o, dm, lim, ctr, stk)
+                                   : mesh_walk<STRICT, false, LOG>(sc, g.aux0, o, dm, lim, g.f[MSH_SCALE], ctr, log, log_cap, log_n,
+                                                                   (uint32_t)g.aux1 << 24);
                 t = r.t;
                 if (t < RT_BIG_DIST) mesh_fill_hit(sc, r.leaf, o, dm, t, tmp);
                 break;
@@ -435,6 +547,23 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
             const double sa = dot(A - Q, N), sl = dot(Lc - Q, N);
             const double tol = 1e-7 * (1.0 + fabs(sa) + fabs(sl));
             if ((sa > tol && sl > Rl + tol) || (sa < -tol && sl < -(Rl + tol))) may = false;
+        } else if (g.type == RT_PRIM_MESH && g.aux0 != RT_REF_END) {
+            // segment A + D*s, 0 <= s <= smax, against the root box grown by the capsule radius
+            const double smax = raw ? s_raw : 1.0, rc = (raw ? r_raw : Rl) + 1e-9 * (1.0 + g.f[MSH_SCALE]);
+            double tlo = 0.0, thi = smax;
+            const double Aa[3] = {A.x, A.y, A.z}, Da[3] = {D.x, D.y, D.z};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const double lo = g.f[MSH_BMIN + k] - rc, hi = g.f[MSH_BMAX + k] + rc;
+                if (fabs(Da[k]) > 1e-200) {
+                    const double i = 1.0 / Da[k], t1 = (lo - Aa[k]) * i, t2 = (hi - Aa[k]) * i;
+                    tlo = fmax(tlo, fmin(t1, t2));
+                    thi = fmin(thi, fmax(t1, t2));
+                } else if (Aa[k] < lo || Aa[k] > hi) {
+                    thi = -1.0;
+                }
+            }
+            if (tlo > thi * (1.0 + 1e-9) + 1e-12) may = false;
         } else {
             const bool stretched = raw && (g.type == RT_PRIM_MESH || g.type == RT_PRIM_TRIANGLE);
             const double smax = stretched ? s_raw : 1.0, rc = stretched ? r_raw : Rl;
@@ -454,7 +583,7 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
 // true = nothing between C and target.  A primitive occludes if dist - its_hit_distance > 1e-6.
 template <bool STRICT>
 DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
-                      Counters& ctr) {
+                      Counters& ctr, uint32_t* stk) {
     const d3 Vv = target - C;
     const double dist = module(Vv);
     const d3 V = Vv / dist;                                  // = normalize(Vv)
@@ -499,7 +628,8 @@ DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int c
                 break;
             case RT_PRIM_TRIANGLE: t = triangle_hit<false>(g, C, dm, tmp); break;
             case RT_PRIM_MESH:
-                t = mesh_walk<STRICT, true, false>(sc, g.aux0, C, dm, dist, g.f[MSH_SCALE], ctr, nullptr, 0, dummy_n, 0).t;
+                t = (!STRICT && g.aux2 && stk) ? mesh_walk_fast<true>(sc, g, C, dm, dist, ctr, stk).t
+                                               : mesh_walk<STRICT, true, false>(sc, g.aux0, C, dm, dist, g.f[MSH_SCALE], ctr, nullptr, 0, dummy_n, 0).t;
                 break;
             default: break;
         }
