@@ -684,7 +684,36 @@ static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g
                 }
                 rmax = std::fmax(rmax, std::fabs(R));
             }
-            if (g.aux1 > 0) {
+            // the true curve (bezier_newton_hit): frame record, then power-basis coefficients
+            // c[j] = C(n,j) * sum_i (-1)^(j-i) C(j,i) P[i] of the control points P[0..n]
+            const int n = p.u.bezier.degree;
+            DevGeom fr, co;
+            std::memset(&fr, 0, sizeof(fr)), std::memset(&co, 0, sizeof(co));
+            fr.aux1 = n;
+            put(fr, BZN_O1, O1), put(fr, BZN_AX, H(p.u.bezier.N)), put(fr, BZN_NX, H(p.u.bezier.Nx)), put(fr, BZN_NY, H(p.u.bezier.Ny));
+            if (n >= 1 && n <= RT_BEZIER_MAX_CTRL - 1) {
+                double binom[RT_BEZIER_MAX_CTRL][RT_BEZIER_MAX_CTRL];
+                for (int a = 0; a <= n; a++) {
+                    binom[a][0] = 1.0;
+                    for (int b = 1; b <= a; b++) binom[a][b] = (b == a) ? 1.0 : binom[a - 1][b - 1] + binom[a - 1][b];
+                }
+                for (int which = 0; which < 2; which++) {
+                    const double* P = which ? p.u.bezier.R : p.u.bezier.Z;
+                    for (int j = 0; j <= n; j++) {
+                        double s = 0.0;
+                        for (int i = 0; i <= j; i++) s += (((j - i) & 1) ? -1.0 : 1.0) * binom[j][i] * P[i];
+                        co.f[(which ? BZN_CR : BZN_CZ) + j] = binom[n][j] * s;
+                    }
+                }
+                for (int i = 0; i <= n; i++) {  // the curve stays inside the hull of its control points
+                    tmin = std::fmin(tmin, p.u.bezier.Z[i]), tmax = std::fmax(tmax, p.u.bezier.Z[i]);
+                    rmax = std::fmax(rmax, std::fabs(p.u.bezier.R[i]));
+                }
+            } else {
+                fr.aux1 = 0;
+            }
+            segs.push_back(fr), segs.push_back(co);
+            if (tmax >= tmin) {
                 double half = 0.5 * (tmax - tmin);
                 set_ball(g, O1 + axis * (0.5 * (tmin + tmax)), std::sqrt(half * half + rmax * rmax));
             }

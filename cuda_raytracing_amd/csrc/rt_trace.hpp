@@ -20,7 +20,7 @@
 struct DevGeom {  // 192 bytes
     int32_t type;
     uint32_t aux0;  // mesh: BVH root ref; bezier: first segment in DevScene::segs
-    int32_t aux1;   // bezier: number of segments; mesh: mesh index
+    int32_t aux1;   // bezier: number of segments (two more records follow them: curve frame, curve coefficients); mesh: mesh index
     int32_t aux2;   // mesh: 1 if the paired-box tree + LDS stack walk may be used (depth fits the stack)
     double f[22];
 };
@@ -234,6 +234,99 @@ DEV double bezier_stacked_hit(const DevScene& sc, const DevGeom RT_CONST& g, d3 
         }
     }
     return cur;
+}
+
+// Bezier surface of revolution proper (RT_F_BEZIER_STACKED cleared): the (z, r) profile is the
+// Bezier curve of all control points, swept around the axis; the surface is open (no caps).  The
+// reference only ever approximates it by the cylinder stack above (its own attempt at the curve,
+// CR/Collision_Bezier.cu:3-198, is dead code), so this intersector has no reference counterpart.
+// In the axis frame the ray is p + t v.  The curve parameter u is found by Newton's method from
+// RT_BZ_SEEDS starting values; t comes from whichever equation is the better conditioned: for a ray
+// mostly along the axis t(u) = (z(u) - pz)/vz and |(p + t v)_xy|^2 = r(u)^2 is solved; for a ray
+// mostly across it t(u) is the near (then far) crossing of the cylinder of radius r(u) and
+// z(u) = pz + t(u) vz is solved.  A candidate counts only if both equations hold to 1e-9.
+// Records: SEGS[aux0 + aux1] holds the frame (BZN_*), the next one the power-basis coefficients
+// (host-computed), both fetched with scalar loads.  Only + - * / sqrt: reproducible bit for bit.
+#define RT_BZ_SEEDS 8
+#define RT_BZ_ITERS 12
+enum { BZN_O1 = 0, BZN_AX = 3, BZN_NX = 6, BZN_NY = 9, BZN_CZ = 0, BZN_CR = RT_BEZIER_MAX_CTRL };
+DEV void bz_horner(const DevGeom RT_CONST& co, int base, int n, double u, double& val, double& der) {
+    double v = co.f[base + n], dv = 0.0;
+    for (int k = n - 1; k >= 0; k--) {
+        dv = dv * u + v;
+        v = v * u + co.f[base + k];
+    }
+    val = v, der = dv;
+}
+template <bool FULL>
+DEV double bezier_newton_hit(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
+    const DevGeom RT_CONST& fr = SEGS(sc)[g.aux0 + g.aux1];
+    const DevGeom RT_CONST& co = SEGS(sc)[g.aux0 + g.aux1 + 1];
+    const int n = fr.aux1;
+    if (n < 1) return RT_BIG_DIST;
+    const d3 ax = G3(fr, BZN_AX), Nx = G3(fr, BZN_NX), Ny = G3(fr, BZN_NY), q = o - G3(fr, BZN_O1);
+    const double pz = dot(q, ax), px = dot(q, Nx), py = dot(q, Ny), vz = dot(V, ax), vx = dot(V, Nx), vy = dot(V, Ny);
+    const double qa = vx * vx + vy * vy, qb = px * vx + py * vy, qc = px * px + py * py;
+    const bool radial = qa > vz * vz;
+    double best_t = RT_BIG_DIST, best_u = 0.0;
+    for (int pass = 0; pass < (radial ? 2 : 1); pass++) {
+        if (pass == 1 && best_t < RT_BIG_DIST) break;  // every near-side crossing precedes every far-side one
+        const double sgn = pass == 0 ? -1.0 : 1.0;
+        for (int s = 0; s < RT_BZ_SEEDS; s++) {
+            double u = (s + 0.5) / RT_BZ_SEEDS, z, r, dz, dr;
+            for (int it = 0; it < RT_BZ_ITERS; it++) {
+                bz_horner(co, BZN_CZ, n, u, z, dz);
+                bz_horner(co, BZN_CR, n, u, r, dr);
+                double F, dF;
+                if (radial) {
+                    double disc = qb * qb - qa * (qc - r * r), sq = 0.0, dt = 0.0;
+                    if (disc > 0.0) {
+                        sq = sqrt(disc);
+                        if (sq > 1e-12) dt = sgn * (r * dr) / sq;
+                    }
+                    double t = (-qb + sgn * sq) / qa;
+                    F = z - pz - t * vz;
+                    dF = dz - vz * dt;
+                } else {
+                    double t = (z - pz) / vz, qx = px + t * vx, qy = py + t * vy;
+                    F = qx * qx + qy * qy - r * r;
+                    dF = 2.0 * (qx * vx + qy * vy) * (dz / vz) - 2.0 * r * dr;
+                }
+                if (fabs(dF) < 1e-14) break;
+                double du = F / dF;
+                u = u - du;
+                if (u < 0.0) u = 0.0;
+                if (u > 1.0) u = 1.0;
+                if (fabs(du) < 1e-13) break;
+            }
+            bz_horner(co, BZN_CZ, n, u, z, dz);
+            bz_horner(co, BZN_CR, n, u, r, dr);
+            double t = RT_BIG_DIST;
+            if (radial) {
+                double disc = qb * qb - qa * (qc - r * r);
+                if (disc >= 0.0) {
+                    double tt = (-qb + sgn * sqrt(disc)) / qa;
+                    if (fabs(z - pz - tt * vz) <= 1e-9 * (1.0 + fabs(z) + fabs(pz))) t = tt;
+                }
+            } else {
+                double tt = (z - pz) / vz, qx = px + tt * vx, qy = py + tt * vy;
+                if (fabs(qx * qx + qy * qy - r * r) <= 1e-9 * (1.0 + r * r)) t = tt;
+            }
+            if (t > RT_EPS && t < best_t) best_t = t, best_u = u;
+        }
+    }
+    if (FULL && best_t < RT_BIG_DIST) {
+        double z, r, dz, dr;
+        bz_horner(co, BZN_CZ, n, best_u, z, dz);
+        bz_horner(co, BZN_CR, n, best_u, r, dr);
+        double qx = px + best_t * vx, qy = py + best_t * vy;
+        d3 erho = unit(Nx * qx + Ny * qy);
+        d3 Nn = unit(erho * dz - ax * dr);
+        h.C = o + V * best_t;
+        h.front = dot(V, Nn) < 0;
+        h.N = h.front ? Nn : -Nn;
+    }
+    return best_t;
 }
 
 // CR/Collision.cu:110-149,267-282 (standalone triangle; the normal is not flipped; d is the
@@ -491,7 +584,11 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
                 if (ball_may_hit(g, o, V, lim)) t = cylinder_hit<true>(g, o, V, tmp);
                 break;
             case RT_PRIM_BEZIER:
-                if (ball_may_hit(g, o, V, RT_BIG_DIST)) t = bezier_stacked_hit<true>(sc, g, o, V, RT_BIG_DIST, tmp);
+                if (!(flags & RT_F_BEZIER_STACKED)) {
+                    if (ball_may_hit(g, o, V, lim)) t = bezier_newton_hit<true>(sc, g, o, V, tmp);
+                } else if (ball_may_hit(g, o, V, RT_BIG_DIST)) {
+                    t = bezier_stacked_hit<true>(sc, g, o, V, RT_BIG_DIST, tmp);
+                }
                 break;
             case RT_PRIM_TRIANGLE: t = triangle_hit<true>(g, o, dm, tmp); break;
             case RT_PRIM_MESH: {
@@ -624,7 +721,11 @@ DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int c
             case RT_PRIM_BEZIER:
                 // the stack's `closest` bookkeeping can return a far segment's distance, so segments
                 // are not pruned by distance here, only by direction
-                if (ball_may_hit(g, C, V, RT_BIG_DIST)) t = bezier_stacked_hit<false>(sc, g, C, V, RT_BIG_DIST, tmp);
+                if (!(flags & RT_F_BEZIER_STACKED)) {
+                    if (ball_may_hit(g, C, V, dist)) t = bezier_newton_hit<false>(sc, g, C, V, tmp);
+                } else if (ball_may_hit(g, C, V, RT_BIG_DIST)) {
+                    t = bezier_stacked_hit<false>(sc, g, C, V, RT_BIG_DIST, tmp);
+                }
                 break;
             case RT_PRIM_TRIANGLE: t = triangle_hit<false>(g, C, dm, tmp); break;
             case RT_PRIM_MESH:

@@ -258,6 +258,118 @@ static int mesh_walk(ctx_t* cx, uint32_t mesh_tag, uint32_t ref, v3 o, v3 d, col
     return f1 || f2;
 }
 
+
+/* ---- Bezier surface of revolution by Newton iteration (RT_F_BEZIER_STACKED cleared) ---------------
+ * The reference's live code approximates the surface by stacked cylinders (CR/Collision_Bezier.cu:
+ * 200-240); its abandoned attempt (:3-198) reduced the problem to a profile curve in 2-D and refined
+ * a parameter guess numerically.  This is that idea done properly, for the surface
+ *     S(u, phi) = O1 + z(u) N + r(u) (cos phi Nx + sin phi Ny),   0 <= u <= 1,
+ * where (z, r)(u) is the Bezier curve of ALL control points P= z r (degree = #points - 1) and
+ * (N, Nx, Ny) the frame the loader stores (CR/primitive.cpp:265-271).  The ray in that frame is
+ * p + t v.  One unknown, u, is found by Newton's method from BZ_SEEDS starting points (BZ_ITERS
+ * steps each, u clamped to [0,1]); the other equation supplies t, chosen for conditioning:
+ *   - ray mostly along the axis (vz^2 >= vx^2+vy^2): t(u) = (z(u) - pz)/vz, solve |(p+tv)_xy|^2 = r(u)^2;
+ *   - ray mostly across it: t(u) = near (then far) crossing of the cylinder of radius r(u) around
+ *     the axis, solve z(u) = pz + t(u) vz.  Every near-side crossing comes before every far-side
+ *     one, so the far side is searched only when the near side yields nothing.
+ * A candidate counts only if both equations hold to 1e-9 (relative).  The smallest
+ * t > 1e-6 wins; the normal is z'(u) e_rho - r'(u) N, turned to face the ray.  The surface is open
+ * (no end caps) and has no texture mapping.  No counterpart runs in the reference, so parity for this
+ * intersector is GPU-versus-this-file only ("unpinned").  The polynomial is evaluated in the power
+ * basis by Horner's rule; only + - * / and sqrt are used, so the device reproduces it bit for bit. */
+#define BZ_SEEDS 8
+#define BZ_ITERS 12
+static void bezier_power_basis(const double* P, int n, double* c) { /* c[j] = C(n,j) sum_i (-1)^(j-i) C(j,i) P[i] */
+    double binom[RT_BEZIER_MAX_CTRL][RT_BEZIER_MAX_CTRL];
+    for (int a = 0; a <= n; a++) {
+        binom[a][0] = 1.0;
+        for (int b = 1; b <= a; b++) binom[a][b] = (b == a) ? 1.0 : binom[a - 1][b - 1] + binom[a - 1][b];
+    }
+    for (int j = 0; j <= n; j++) {
+        double s = 0.0;
+        for (int i = 0; i <= j; i++) s += (((j - i) & 1) ? -1.0 : 1.0) * binom[j][i] * P[i];
+        c[j] = binom[n][j] * s;
+    }
+}
+static void horner2(const double* c, int n, double u, double* val, double* der) {
+    double v = c[n], dv = 0.0;
+    for (int k = n - 1; k >= 0; k--) {
+        dv = dv * u + v;
+        v = v * u + c[k];
+    }
+    *val = v, *der = dv;
+}
+static void bezier_newton_intersect(const rt_primitive* p, v3 o, v3 d, col_t* c) {
+    const int n = p->u.bezier.degree;
+    if (n < 1 || n > RT_BEZIER_MAX_CTRL - 1) return;
+    double cz[RT_BEZIER_MAX_CTRL], cr[RT_BEZIER_MAX_CTRL];
+    bezier_power_basis(p->u.bezier.Z, n, cz);
+    bezier_power_basis(p->u.bezier.R, n, cr);
+    const v3 Vv = unit(d), ax = p->u.bezier.N, Nx = p->u.bezier.Nx, Ny = p->u.bezier.Ny, q = sub(o, p->u.bezier.O1);
+    const double pz = dot(q, ax), px = dot(q, Nx), py = dot(q, Ny), vz = dot(Vv, ax), vx = dot(Vv, Nx), vy = dot(Vv, Ny);
+    const double qa = vx * vx + vy * vy, qb = px * vx + py * vy, qc = px * px + py * py;
+    const int radial = qa > vz * vz;
+    double best_t = RT_BIG_DIST, best_u = 0.0;
+    for (int pass = 0; pass < (radial ? 2 : 1); pass++) {
+        if (pass == 1 && best_t < RT_BIG_DIST) break; /* every near-side crossing precedes every far-side one */
+        const double sgn = pass == 0 ? -1.0 : 1.0;
+        for (int g = 0; g < BZ_SEEDS; g++) {
+            double u = (g + 0.5) / BZ_SEEDS, z, r, dz, dr;
+            for (int it = 0; it < BZ_ITERS; it++) {
+                horner2(cz, n, u, &z, &dz);
+                horner2(cr, n, u, &r, &dr);
+                double F, dF;
+                if (radial) {
+                    double disc = qb * qb - qa * (qc - r * r), sq = 0.0, dt = 0.0;
+                    if (disc > 0.0) {
+                        sq = sqrt(disc);
+                        if (sq > 1e-12) dt = sgn * (r * dr) / sq;
+                    }
+                    double t = (-qb + sgn * sq) / qa;
+                    F = z - pz - t * vz;
+                    dF = dz - vz * dt;
+                } else {
+                    double t = (z - pz) / vz, qx = px + t * vx, qy = py + t * vy;
+                    F = qx * qx + qy * qy - r * r;
+                    dF = 2.0 * (qx * vx + qy * vy) * (dz / vz) - 2.0 * r * dr;
+                }
+                if (fabs(dF) < 1e-14) break;
+                double du = F / dF;
+                u = u - du;
+                if (u < 0.0) u = 0.0;
+                if (u > 1.0) u = 1.0;
+                if (fabs(du) < 1e-13) break;
+            }
+            horner2(cz, n, u, &z, &dz);
+            horner2(cr, n, u, &r, &dr);
+            double t = RT_BIG_DIST;
+            if (radial) {
+                double disc = qb * qb - qa * (qc - r * r);
+                if (disc >= 0.0) {
+                    double tt = (-qb + sgn * sqrt(disc)) / qa;
+                    if (fabs(z - pz - tt * vz) <= 1e-9 * (1.0 + fabs(z) + fabs(pz))) t = tt;
+                }
+            } else {
+                double tt = (z - pz) / vz, qx = px + tt * vx, qy = py + tt * vy;
+                if (fabs(qx * qx + qy * qy - r * r) <= 1e-9 * (1.0 + r * r)) t = tt;
+            }
+            if (t > RT_EPS && t < best_t) best_t = t, best_u = u;
+        }
+    }
+    if (best_t < RT_BIG_DIST) {
+        double z, r, dz, dr;
+        horner2(cz, n, best_u, &z, &dz);
+        horner2(cr, n, best_u, &r, &dr);
+        double qx = px + best_t * vx, qy = py + best_t * vy;
+        v3 erho = unit(add(mulk(Nx, qx), mulk(Ny, qy)));
+        v3 Nn = unit(sub(mulk(erho, dz), mulk(ax, dr)));
+        c->hit = 1, c->dist = best_t, c->C = add(o, mulk(Vv, best_t));
+        c->front = dot(Vv, Nn) < 0;
+        c->N = c->front ? Nn : neg(Nn);
+    }
+}
+void orc_bezier_power_basis(const double* P, int n, double* c) { bezier_power_basis(P, n, c); }
+
 /* CR/Collision.cu:151-291 (+ CR/primitive.cpp:109-138,159-175,192-227 for the CPU twins) */
 static int prim_intersect(ctx_t* cx, int pi, v3 o, v3 d, col_t* c) {
     const rt_primitive* p = &cx->sc->primitives[pi];
@@ -312,6 +424,10 @@ static int prim_intersect(ctx_t* cx, int pi, v3 o, v3 d, col_t* c) {
             cylinder_intersect(p->u.cylinder.O1, p->u.cylinder.O2, p->u.cylinder.R, o, d, c);
             break;
         case RT_PRIM_BEZIER: { /* CR/Collision_Bezier.cu:200-240, `closest` bookkeeping included */
+            if (!(cx->flags & RT_F_BEZIER_STACKED)) {
+                bezier_newton_intersect(p, o, d, c);
+                break;
+            }
             double closest = 1e10;
             for (int i = 0; i < p->u.bezier.degree; i++) {
                 v3 axis = unit(sub(p->u.bezier.O2, p->u.bezier.O1)), p1, p2;

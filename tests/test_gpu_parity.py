@@ -62,6 +62,9 @@ def test_cpu_ref_mode_against_reference_fixtures(name):
     ("t_icosa", abi.RT_MODE_CPU_REF, 2, False),
     ("t_cpu_features", abi.RT_MODE_GPU_REF, 3, True),
     ("t_grammar_quirks", abi.RT_MODE_GPU_REF, 1, False),
+    ("t_bezier", abi.RT_MODE_GPU_REF, 2, True),                                  # stacked-cylinder Bezier
+    ("t_bezier", abi.RT_MODE_GPU_REF & ~abi.RT_F_BEZIER_STACKED, 2, True),       # true surface of revolution
+    ("c5_final", abi.RT_MODE_GPU_REF & ~abi.RT_F_BEZIER_STACKED, 1, False),
 ])
 def test_full_render_against_oracle(name, flags, spp, dof):
     hs = scene(name)
@@ -114,6 +117,22 @@ def test_mesh_scenes_against_oracle_and_pruned_equals_strict(name, W, H, spp):
     assert np.array_equal(fast, strict), "pruned traversal changed the image"
     assert fstats.rays == sstats.rays
     assert fstats.nodes_visited < sstats.nodes_visited
+
+
+@pytest.mark.parametrize("stacked", [True, False])
+def test_bezier_primary_hits_bit_exact(stacked):
+    """Both Bezier intersectors use only + - * / sqrt: hit ids and distances must equal the oracle's bit for bit."""
+    hs = scene("t_bezier")
+    W, H = 192, 144
+    flags = abi.RT_MODE_GPU_REF if stacked else abi.RT_MODE_GPU_REF & ~abi.RT_F_BEZIER_STACKED
+    st = orc.settings(flags=flags)
+    o_hit, o_t, _, _, _ = orc.trace_primary(hs, st, W, H)
+    with device_scene(hs) as ds:
+        hit, t, _, _, _ = ds.trace_primary(st, W, H)
+    bez = [i for i in range(hs.desc.n_primitives) if hs.desc.primitives[i].type == abi.RT_PRIM_BEZIER]
+    assert all((o_hit == i).sum() > 100 for i in bez), "scene does not show both Bezier primitives"
+    assert np.array_equal(hit, o_hit)
+    assert same_double(t, o_t)
 
 
 @pytest.mark.parametrize("spp", [1, 3, 32, 64, 100])

@@ -69,3 +69,94 @@ def test_oracle_image_independent_of_threads_and_tiles():
         img[y0:y0 + h, x0:x0 + w] = part[y0:y0 + h, x0:x0 + w]
         total += s.rays
     assert np.array_equal(img, full) and total == s_full.rays
+
+
+# ---- Bezier surface of revolution (no reference counterpart: parity unpinned, analytic checks only) -----
+
+BEZ_HEAD = """background
+ color= 0 0 0
+end
+camera
+ O= 0.3 -10 1.2
+ N= 0 1 -0.02
+ image_W= 64
+ image_H= 48
+end
+light point
+ O= 0 -10 10
+ color= 1 1 1
+end
+"""
+
+
+def _scene_from_text(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return HostScene(str(p))
+
+
+def test_bezier_newton_straight_profile_is_a_cylinder_body(tmp_path):
+    """A constant-radius profile swept around the axis is an open cylinder: wherever the oracle's cylinder
+    reports a body hit, the Newton intersector must report the same distance."""
+    bez = _scene_from_text(tmp_path, "b.txt", BEZ_HEAD + "primitive bezier\n O1= 0 0 0\n O2= 0 0 2\n P= 0 0.5\n P= 0.7 0.5\n P= 2 0.5\n diff= 1\nend\n")
+    cyl = _scene_from_text(tmp_path, "c.txt", BEZ_HEAD + "primitive cylinder\n O1= 0 0 0\n O2= 0 0 2\n R= 0.5\n diff= 1\nend\n")
+    st = orc.settings(flags=abi.RT_F_NORMALIZE_PRIMARY)
+    hb, tb, _, _, _ = orc.trace_primary(bez, st, 64, 48)
+    hc, tc, _, _, _ = orc.trace_primary(cyl, st, 64, 48)
+    assert (hc >= 0).sum() > 50
+    assert np.array_equal(hb >= 0, hc >= 0)   # the camera looks from the side: no cap is visible
+    m = hc >= 0
+    assert np.abs(tb[m] - tc[m]).max() < 1e-10
+
+
+def test_bezier_newton_cone_profile_matches_the_analytic_cone(tmp_path):
+    """A linear profile r = 1 - z/4 (0 <= z <= 2) is a truncated cone; compare with the closed form."""
+    hs = _scene_from_text(tmp_path, "k.txt", BEZ_HEAD + "primitive bezier\n O1= 0 0 0\n O2= 0 0 2\n P= 0 1\n P= 2 0.5\n diff= 1\nend\n")
+    st = orc.settings(flags=abi.RT_F_NORMALIZE_PRIMARY)
+    W, H = 64, 48
+    hit, t, _, _, _ = orc.trace_primary(hs, st, W, H)
+    cam = hs.desc.camera
+    O = np.array([cam.O.x, cam.O.y, cam.O.z])
+    N = np.array([cam.N.x, cam.N.y, cam.N.z])
+    Dx = np.array([cam.Dx.x, cam.Dx.y, cam.Dx.z])
+    Dy = np.array([cam.Dy.x, cam.Dy.y, cam.Dy.z])
+    n_checked = 0
+    for y in range(H):
+        for x in range(W):
+            # primary ray of pixel (x, y): CR/camera.cpp:57-59
+            V = N + Dy * (2 * y / H - 1) + Dx * (2 * x / W - 1)
+            V /= np.linalg.norm(V)
+            # |(O + tV)_xy|^2 = (1 - (Oz + t Vz)/4)^2
+            k = 1 - O[2] / 4
+            a = V[0] ** 2 + V[1] ** 2 - V[2] ** 2 / 16
+            b = 2 * (O[0] * V[0] + O[1] * V[1]) + 2 * k * V[2] / 4
+            c = O[0] ** 2 + O[1] ** 2 - k * k
+            disc = b * b - 4 * a * c
+            want = None
+            if disc >= 0:
+                for r in sorted([(-b - disc ** 0.5) / (2 * a), (-b + disc ** 0.5) / (2 * a)]):
+                    z = O[2] + r * V[2]
+                    if r > 1e-6 and 0 <= z <= 2:
+                        want = r
+                        break
+            if want is None:
+                continue
+            zc = O[2] + want * V[2]
+            if min(zc, 2 - zc) < 1e-3:
+                continue  # on the rim, either answer is legitimate
+            assert hit[y, x] >= 0, (x, y)
+            assert abs(t[y, x] - want) < 1e-9, (x, y, t[y, x], want)
+            n_checked += 1
+    assert n_checked > 100
+
+
+def test_bezier_power_basis_equals_bernstein_form():
+    from math import comb
+    rng = np.random.default_rng(5)
+    for n in range(1, 10):
+        P = rng.uniform(-2, 3, n + 1)
+        c = np.zeros(n + 1)
+        orc.load().orc_bezier_power_basis(C.c_void_p(P.ctypes.data), n, C.c_void_p(c.ctypes.data))
+        for u in np.linspace(0, 1, 11):
+            bern = sum(comb(n, i) * u ** i * (1 - u) ** (n - i) * P[i] for i in range(n + 1))
+            assert abs(np.polyval(c[::-1], u) - bern) < 1e-9 * (1 + abs(bern)) * 4 ** n
