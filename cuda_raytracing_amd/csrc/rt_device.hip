@@ -28,7 +28,7 @@
 #include "rt_trace.hpp"
 
 static_assert(sizeof(rt_bvh_node) == 64 && sizeof(rt_bvh_leaf) == 96, "BVH record sizes are part of the ABI");
-static_assert(sizeof(DevNode2) == 128 && sizeof(DevGeom) == 192, "device record sizes");
+static_assert(sizeof(DevNode4) == 128 && sizeof(DevGeom) == 192, "device record sizes");
 static_assert(sizeof(rt_primitive) == 408 && sizeof(rt_light) == 112 && sizeof(rt_scene_desc) == 256 && sizeof(rt_settings) == 40 &&
                   sizeof(rt_stats) == 80,
               "record sizes are part of the ABI (the Python binding mirrors them)");
@@ -37,23 +37,34 @@ struct Tile {
     int32_t x0, y0, w, h;
 };
 
+// Work decomposition.  Pixels of a tile are numbered in 8x8 blocks ("slots" 0..63 inside a block, row-major);
+// blocks are numbered tile after tile.  A task is a run of slots inside one block; the first blocks are cut
+// into long tasks, the last ones into shorter and shorter ones so that the waves run dry together:
+//   blocks [0, bA)   : 64 / sA tasks of sA slots each
+//   blocks [bA, bB)  : 64 / sB tasks of sB slots
+//   blocks [bB, nb)  : 64 / sC tasks of sC slots          (sA >= sB >= sC, powers of two)
 struct RenderParams {
     DevScene sc;
     int32_t tex_w, tex_h, spp, dof;
     double focal, aperture;
     uint32_t k0, k1, flags;
-    int32_t n_tiles, ppt;  // ppt = pixels per task
-    uint32_t n_tasks;
+    int32_t n_tiles;
+    uint32_t n_tasks, bA, bB, tA, tB;
+    int32_t sA, sB, sC;
     const Tile* tiles;
-    const uint32_t* tile_prefix;  // n_tiles + 1 entries: first task of each tile
+    const uint32_t* tile_prefix;  // n_tiles + 1 entries: first block of each tile
     uint32_t* queue;
-    uint8_t* out;  // tex_w * tex_h * 4, row 0 = bottom
+    uint8_t* out;      // tex_w * tex_h * 4, row 0 = bottom
+    double* path_buf;  // RT_BATCH_PATHS * 3 doubles per wave of the grid: colours of finished paths
     unsigned long long* counters;
 };
+#ifndef RT_BATCH_PATHS
+#define RT_BATCH_PATHS 2048  // paths one wave keeps in flight + waiting in one task round
+#endif
 
 enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT,
        // lane-utilisation probes, only counted in -DRT_UTIL_COUNTERS builds (printed by rt_render_* to stderr)
-       CTR_U_SHADOW_SLOTS = CTR_COUNT, CTR_U_SHADOW_ITEMS, CTR_U_TRACE_SLOTS, CTR_U_TRACE_ACTIVE, CTR_ALL };
+       CTR_U_SHADOW_SLOTS = CTR_COUNT, CTR_U_SHADOW_ITEMS, CTR_U_TRACE_SLOTS, CTR_U_TRACE_ACTIVE, CTR_U_PROBES, CTR_ALL = CTR_U_PROBES + 12 };
 
 // ---- camera: CR/RayTracer.cu:52-61, CR/camera.cpp:57-59 -------------------------------------------
 DEV d3 emit(const DevScene& sc, double x, double y) {
@@ -95,6 +106,7 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
         if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, h, ctr));
         ctr.shaded++;
     }
+    RT_LAP(ctr, PF_SHADE_SETUP);
     uint32_t off = 0;
     for (int l = 0; l < sc.n_lights; l++) {
         const rt_light RT_CONST& L = LIGHTS(sc)[l];
@@ -119,9 +131,13 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
                 if (cand == 0ull) work = false, cnt = n_l;
             }
         }
-        const unsigned long long wmask = __ballot(work);
-        const int nwork = __popcll(wmask);
-        const int my_rank = work ? rank_in(wmask) : nwork + rank_in(~wmask);
+        RT_LAP(ctr, PF_CAND);
+        // slots are dealt to the points that may be shadowed by a mesh first, so that the lanes of a chunk
+        // walk the BVH together instead of waiting for the few that do
+        const bool heavy = work && (STRICT || (cand & sc.mesh_mask) != 0ull);
+        const unsigned long long wmask = __ballot(work), hmask = __ballot(heavy), lmask = wmask & ~hmask;
+        const int nwork = __popcll(wmask), nheavy = __popcll(hmask);
+        const int my_rank = heavy ? rank_in(hmask) : work ? nheavy + rank_in(lmask) : nwork + rank_in(~wmask);
         const int owner_tbl = __builtin_amdgcn_ds_permute(my_rank << 2, lane);  // lane r learns which lane owns slot r
         const int total = nwork * n_l;
         for (int base = 0; base < total; base += 64) {
@@ -139,6 +155,7 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
             const uint32_t opix = __shfl(pixel, owner, 64), osmp = __shfl(smp, owner, 64), odraw = __shfl(draw, owner, 64);
             const unsigned long long ocand = STRICT ? ~0ull : __shfl(cand, owner, 64);
             bool clear = false;
+            RT_LAP(ctr, PF_CHUNK_SHFL);
             if (act) {
                 d3 target = d3{L.O.x, L.O.y, L.O.z};
 #ifdef RT_ABLATE_RNG
@@ -150,8 +167,10 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
                     frand_pair(P.k0, P.k1, opix, osmp, odraw + off + 2u * (uint32_t)si, fa, fb);
                     target = light_sample(L, fa, fb);
                 }
+                RT_LAP(ctr, PF_RNG);
                 clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, ctr, stk);
             }
+            RT_LAP(ctr, PF_SH_PRIMS);
             const unsigned long long cm = __ballot(clear);
             if (work) {
                 int lo = my_rank * n_l - base, hi = lo + n_l;
@@ -163,6 +182,7 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
                 }
             }
         }
+        RT_LAP(ctr, PF_CHUNK_SHFL);
         if (need) {
             double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
             if (!(shade < RT_EPS)) {
@@ -183,6 +203,7 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
             }
         }
         if (!point) off += 2u * (uint32_t)n_l;
+        RT_LAP(ctr, PF_SHADE_MATH);
     }
     if (need) draw += off;
     return ret;
@@ -191,20 +212,74 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
 // ---- one path per lane: CR/Scene.cu:23-58 + CR/Scene_Material.cu:68-118 as a loop ----------------
 enum { ST_REFL = 1, ST_REFR = 2, ST_PENDING_REFR = 4, ST_FRONT = 8 };
 
+// One round of a task: `n_slots` pixel slots x samples [s_begin, s_end).  Path p of the round is
+// sample s_begin + p % ns of slot slot0 + p / ns.  The wave keeps up to 64 paths in flight, one per
+// lane; a lane whose path has ended takes the next unstarted one, so the lanes stay busy until the
+// round runs out ("path regeneration").  Finished colours go to buf[p].
 template <bool STRICT>
-DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t smp, d3 o, d3 d, uint32_t draw, Counters& ctr,
-                   uint32_t* stk) {
+DEV void trace_batch(const RenderParams& P, const Tile tile, int blk_in_tile, int slot0, int n_slots, int s_begin, int s_end,
+                     double* buf, Counters& ctr, uint32_t* stk) {
     const DevScene& sc = P.sc;
+    const int ns = s_end - s_begin;
+    const int n_paths = n_slots * ns;
+    const int nbx = (tile.w + 7) >> 3;
+    const int bx0 = tile.x0 + (blk_in_tile % nbx) * 8, by0 = tile.y0 + (blk_in_tile / nbx) * 8;
     // frame k = the hit at depth k+1 that is waiting for a child ray to return
     double f_acc[RT_MAX_DEPTH][3], f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3], f_dist[RT_MAX_DEPTH];
     int32_t f_prim[RT_MAX_DEPTH];
     uint32_t f_stage[RT_MAX_DEPTH];
-    int sp = 0;
-    bool tracing = active;
-    d3 final_c = D3(0, 0, 0);
-    uint32_t no_log = 0;
+    int sp = 0, my_path = 0, next = 0;
+    bool tracing = false;
+    uint32_t pixel = 0, smp = 0, draw = 0, no_log = 0;
+    d3 o = D3(0, 0, 0), d = D3(0, 0, 1);
 
-    while (__ballot(tracing) != 0ull) {
+    for (;;) {
+        // ---- idle lanes start the next paths of the round (CR/RayTracer.cu:52-72) ----
+        if (next < n_paths) {
+            const unsigned long long idle = __ballot(!tracing);
+            const int p = next + rank_in(idle);
+            if (!tracing && p < n_paths) {
+                const int q = p / ns, s = s_begin + (p - q * ns), inb = slot0 + q;
+                const int px = bx0 + (inb & 7), py = by0 + (inb >> 3);
+                if (px < tile.x0 + tile.w && py < tile.y0 + tile.h) {
+                    int x, y;
+                    map_pixel(P, px, py, x, y);
+                    const d3 dc = unit(emit(sc, x, y));
+                    pixel = (uint32_t)py * (uint32_t)P.tex_w + (uint32_t)px;
+                    smp = (uint32_t)s;
+                    my_path = p, sp = 0, draw = 0, tracing = true;
+                    o = sc.camO, d = dc;
+                    if (P.spp == 1) {
+                        if (!(P.flags & RT_F_NORMALIZE_PRIMARY)) d = emit(sc, x, y);
+                    } else {
+                        float fu, fv;
+                        frand_pair(P.k0, P.k1, pixel, smp, 0u, fu, fv);
+                        draw = 2;
+                        double u = x + (2.0f * fu - 1.0f);
+                        double v = y + (2.0f * fv - 1.0f);
+                        d = emit(sc, u, v);
+                        if (P.flags & RT_F_NORMALIZE_PRIMARY) d = unit(d);
+                    }
+                    if (P.dof) {  // modifyRayForDepthOfField, CR/RayTracer.cu:31-38
+                        const d3 focal = sc.camO + dc * P.focal;
+                        float fa, fb;
+                        frand_pair(P.k0, P.k1, pixel, smp, draw, fa, fb);
+                        draw += 2;
+                        double rx = (fa - 0.5) * P.aperture / 10.0;
+                        double ry = (fb - 0.5) * P.aperture / 10.0;
+                        o = o + (sc.camDx * rx + sc.camDy * ry);
+                        d = unit(focal - o);
+                    }
+                }
+            }
+            next += __popcll(idle);
+        }
+        if (__ballot(tracing) == 0ull) {
+            if (next >= n_paths) break;
+            continue;  // every slot just handed out lies outside the tile
+        }
+        RT_LAP(ctr, PF_TASK);
+
         Hit h;
         h.prim = -1, h.leaf = -1, h.dist = RT_BIG_DIST, h.front = false, h.N = D3(0, 0, 0), h.C = D3(0, 0, 0);
         bool surface = false;
@@ -226,6 +301,7 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
                 surface = true;
             }
         }
+        RT_LAP(ctr, PF_CLOSEST_PRIMS);
         bool need_shade = false;
         if (surface) {
             const rt_material& m = sc.prims[h.prim].material;
@@ -289,8 +365,9 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
             }
             // hand `result` to the frames that wait for it
             while (have_result) {
-                if (sp == 0) {
-                    final_c = result;
+                if (sp == 0) {  // the path is complete
+                    double* dst = buf + (size_t)my_path * 3;
+                    dst[0] = result.x, dst[1] = result.y, dst[2] = result.z;
                     tracing = false;
                     break;
                 }
@@ -323,8 +400,8 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
                 }
             }
         }
+        RT_LAP(ctr, PF_FRAME);
     }
-    return final_c;
 }
 
 // ---- the render kernel: CR/RayTracer.cu:40-94 --------------------------------------------------
@@ -334,7 +411,6 @@ DEV d3 trace_paths(const RenderParams& P, bool active, uint32_t pixel, uint32_t 
 template <bool STRICT>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
     const int lane = lane_id();
-    const DevScene& sc = P.sc;
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
     __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
     uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
@@ -342,83 +418,75 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     ctr.rays_secondary = ctr.rays_shadow = ctr.nodes = ctr.tris = ctr.shaded = ctr.texfetch = 0;
 #ifdef RT_UTIL_COUNTERS
     ctr.u_shadow_slots = ctr.u_shadow_items = ctr.u_trace_slots = ctr.u_trace_active = 0;
+    for (int i = 0; i < 12; i++) ctr.u[i] = 0;
+    __shared__ unsigned long long s_prof[4][1 + PF_COUNT];
+    ctr.prof = s_prof[threadIdx.x >> 6];
+    if (lane < 1 + PF_COUNT) ctr.prof[lane] = lane == 0 ? __builtin_readcyclecounter() : 0ull;
 #endif
     const int spp = P.spp;
-    const int group = spp <= 64 ? spp : 64;        // lanes per pixel within one pass
-    const int passes = spp <= 64 ? 1 : (spp + 63) / 64;
-    const int slot = lane / group, sub = lane - slot * group;
+    double* buf = P.path_buf + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t)(RT_BATCH_PATHS * 3);
 
     for (;;) {
         uint32_t task = 0;
         if (lane == 0) task = atomicAdd(P.queue, 1u);
         task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
         if (task >= P.n_tasks) break;
+        // task -> (block, first slot, slots)
+        uint32_t blk;
+        int S, per, sub;
+        if (task < P.tA) {
+            S = P.sA, per = 64 / S, blk = task / (uint32_t)per, sub = (int)(task % (uint32_t)per);
+        } else if (task < P.tB) {
+            const uint32_t u = task - P.tA;
+            S = P.sB, per = 64 / S, blk = P.bA + u / (uint32_t)per, sub = (int)(u % (uint32_t)per);
+        } else {
+            const uint32_t u = task - P.tB;
+            S = P.sC, per = 64 / S, blk = P.bB + u / (uint32_t)per, sub = (int)(u % (uint32_t)per);
+        }
         int lo = 0, hi = P.n_tiles;
         while (hi - lo > 1) {
             int mid = (lo + hi) >> 1;
-            if (P.tile_prefix[mid] <= task) lo = mid;
+            if (P.tile_prefix[mid] <= blk) lo = mid;
             else hi = mid;
         }
         const Tile tile = P.tiles[lo];
-        const uint32_t local = task - P.tile_prefix[lo];
-        // pixels of a tile are numbered in 8x8 blocks, row-major inside a block
+        const int blk_in_tile = (int)(blk - P.tile_prefix[lo]);
+        const int slot0 = sub * S;
         const int nbx = (tile.w + 7) >> 3;
-        const uint32_t q = local * (uint32_t)P.ppt + (uint32_t)slot;
-        const int blk = (int)(q >> 6), inb = (int)(q & 63u);
-        const int px = tile.x0 + (blk % nbx) * 8 + (inb & 7), py = tile.y0 + (blk / nbx) * 8 + (inb >> 3);
-        const bool valid = slot < P.ppt && px < tile.x0 + tile.w && py < tile.y0 + tile.h;
-        const uint32_t pixel = (uint32_t)py * (uint32_t)P.tex_w + (uint32_t)px;
-
-        int x = 0, y = 0;
-        d3 dc = D3(0, 0, 1), focal = D3(0, 0, 0);
-        if (valid) {
-            map_pixel(P, px, py, x, y);
-            dc = unit(emit(sc, x, y));
-            focal = sc.camO + dc * P.focal;
-        }
+        // samples per round: everything at once if the colours fit the wave's buffer, else one slot in rounds
+        const int round = (S * spp <= RT_BATCH_PATHS) ? spp : RT_BATCH_PATHS;
         d3 acc = D3(0, 0, 0);
-        for (int pass = 0; pass < passes; pass++) {
-            const int s = pass * 64 + sub;
-            const bool active = valid && s < spp;
-            d3 o = sc.camO, d = dc;
-            uint32_t draw = 0;
-            if (active) {
-                if (spp == 1) {
-                    if (!(P.flags & RT_F_NORMALIZE_PRIMARY)) d = emit(sc, x, y);
-                } else {
-                    float fu, fv;
-                    frand_pair(P.k0, P.k1, pixel, (uint32_t)s, 0u, fu, fv);
-                    draw = 2;
-                    double u = x + (2.0f * fu - 1.0f);
-                    double v = y + (2.0f * fv - 1.0f);
-                    d = emit(sc, u, v);
-                    if (P.flags & RT_F_NORMALIZE_PRIMARY) d = unit(d);
-                }
-                if (P.dof) {  // modifyRayForDepthOfField, CR/RayTracer.cu:31-38
-                    float fa, fb;
-                    frand_pair(P.k0, P.k1, pixel, (uint32_t)s, draw, fa, fb);
-                    draw += 2;
-                    double rx = (fa - 0.5) * P.aperture / 10.0;
-                    double ry = (fb - 0.5) * P.aperture / 10.0;
-                    o = o + (sc.camDx * rx + sc.camDy * ry);
-                    d = unit(focal - o);
-                }
+        for (int s0 = 0; s0 < spp; s0 += round) {
+            const int s1 = s0 + round < spp ? s0 + round : spp;
+            trace_batch<STRICT>(P, tile, blk_in_tile, slot0, S, s0, s1, buf, ctr, stk);
+            // Pixel sums: lane j adds the samples of slot j in sample order (the reference adds them in that order
+            // inside one thread, CR/RayTracer.cu:74-84).  The colours were written by other lanes of this wave; a
+            // fence of work-group scope orders them before the reads without flushing the CU's vector cache, which
+            // the other waves are walking the BVH through.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            const int ns = s1 - s0;
+            for (int j = lane; j < S; j += 64) {  // S <= 64: one pass
+                const double* src = buf + (size_t)j * ns * 3;
+                for (int k = 0; k < ns; k++) acc = acc + D3(src[3 * k], src[3 * k + 1], src[3 * k + 2]);
             }
-            d3 col = trace_paths<STRICT>(P, active, pixel, (uint32_t)s, o, d, draw, ctr, stk);
-            // add this pass's samples in sample order
-            const int n_here = (spp - pass * 64) < group ? (spp - pass * 64) : group;
-            const int first = slot * group;
-            for (int j = 0; j < n_here; j++) acc = acc + shfl_d3(col, (first + j) & 63);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next round overwrites the buffer
         }
-        if (spp > 1) acc = acc / (double)spp;
-        if (valid && sub == 0) {
-            uint32_t rgba = to_u8(acc.x) | (to_u8(acc.y) << 8) | (to_u8(acc.z) << 16) | 0xFF000000u;
-            *reinterpret_cast<uint32_t*>(P.out + (size_t)pixel * 4) = rgba;
+        if (lane < S) {
+            const int inb = slot0 + lane;
+            const int px = tile.x0 + (blk_in_tile % nbx) * 8 + (inb & 7), py = tile.y0 + (blk_in_tile / nbx) * 8 + (inb >> 3);
+            if (px < tile.x0 + tile.w && py < tile.y0 + tile.h) {
+                if (spp > 1) acc = acc / (double)spp;
+                uint32_t rgba = to_u8(acc.x) | (to_u8(acc.y) << 8) | (to_u8(acc.z) << 16) | 0xFF000000u;
+                *reinterpret_cast<uint32_t*>(P.out + ((size_t)py * (size_t)P.tex_w + (size_t)px) * 4) = rgba;
+            }
         }
     }
 #ifdef RT_UTIL_COUNTERS
+    RT_LAP(ctr, PF_TASK);
+    if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);
     unsigned long long v[CTR_ALL] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch,
-                                     ctr.u_shadow_slots, ctr.u_shadow_items, ctr.u_trace_slots, ctr.u_trace_active};
+                                     ctr.u_shadow_slots, ctr.u_shadow_items, ctr.u_trace_slots, ctr.u_trace_active,
+                                     ctr.u[0], ctr.u[1], ctr.u[2], ctr.u[3], ctr.u[4], ctr.u[5], ctr.u[6], ctr.u[7], ctr.u[8], ctr.u[9], ctr.u[10], ctr.u[11]};
     const int n_ctr = CTR_ALL;
 #else
     unsigned long long v[CTR_COUNT] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch};
@@ -482,6 +550,8 @@ struct rt_scene {
     unsigned long long* counters = nullptr;  // CTR_COUNT work counters
     uint8_t* image = nullptr;              // staging image for host destinations
     size_t image_bytes = 0;
+    double* path_buf = nullptr;            // colours of finished paths, RT_BATCH_PATHS per wave of the grid
+    size_t path_buf_bytes = 0;
     Tile* tiles = nullptr;                 // tile list + prefix of the current call
     uint32_t* prefix = nullptr;
     size_t tiles_cap = 0;
@@ -597,49 +667,124 @@ static void cylinder_geom(DevGeom& g, hostmath::h3 O1, hostmath::h3 O2, double R
     set_ball(g, (O1 + O2) * 0.5, std::sqrt(half * half + R * R));
 }
 
-// depth of the subtree under `root` (links were validated to run forward, so this terminates)
-static uint32_t measured_depth(const rt_scene_desc* d, uint32_t root) {
-    if (root == RT_REF_END || (root & RT_REF_LEAF)) return 0;
-    std::vector<std::pair<uint32_t, uint32_t>> st{{root, 0u}};
-    uint32_t best = 0;
-    while (!st.empty()) {
-        auto [ref, dep] = st.back();
-        st.pop_back();
-        best = std::max(best, dep);
-        if (ref == RT_REF_END || (ref & RT_REF_LEAF)) continue;
-        st.push_back({d->nodes[ref].left, dep + 1});
-        st.push_back({d->nodes[ref].right, dep + 1});
-    }
-    return best;
+// ---- four-wide tree of the pruned walk (DevNode4) -------------------------------------------------
+static float round_down(double x) {
+    float f = (float)x;
+    return (double)f > x ? std::nextafterf(f, -INFINITY) : f;
+}
+static float round_up(double x) {
+    float f = (float)x;
+    return (double)f < x ? std::nextafterf(f, INFINITY) : f;
 }
 
-// paired-box copy of the interior nodes (DevNode2): child boxes from the children themselves
-static void build_nodes2(const rt_scene_desc* d, std::vector<DevNode2>& out) {
-    out.assign(d->n_nodes, DevNode2{});
+struct Tree4 {
+    std::vector<DevNode4> nodes;
+    std::vector<uint32_t> node_parent, leaf_parent;   // per binary node / per leaf
+    std::vector<int32_t> mesh_root4;                  // per mesh: root DevNode4 index, -1 = use the stackless walk
+};
+
+// double-precision bounds of what hangs under a child ref: the reference's box of an interior node, the
+// triangle's own bounds for a leaf
+static void ref_bounds(const rt_scene_desc* d, uint32_t ref, double lo[3], double hi[3]) {
+    if (ref & RT_REF_LEAF) {
+        const rt_bvh_leaf& lf = d->leaves[ref & ~RT_REF_LEAF];
+        const double v[3][3] = {{lf.O1.x, lf.O1.y, lf.O1.z}, {lf.O2.x, lf.O2.y, lf.O2.z}, {lf.O3.x, lf.O3.y, lf.O3.z}};
+        for (int k = 0; k < 3; k++) lo[k] = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k])), hi[k] = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+    } else {
+        for (int k = 0; k < 3; k++) lo[k] = d->nodes[ref].bmin[k], hi[k] = d->nodes[ref].bmax[k];
+    }
+}
+
+// Collapse each mesh's binary tree two levels at a time.  A mesh keeps the four-wide walk only if
+// every box is finite, of moderate size and contains the boxes directly below it (the walk's argument
+// for keeping a hit relies on that nesting) and the collapsed tree fits the traversal stack.
+static void build_tree4(const rt_scene_desc* d, Tree4& T) {
+    T.nodes.clear();
+    T.node_parent.assign(d->n_nodes, RT_REF_END);
+    T.leaf_parent.assign(d->n_leaves, RT_REF_END);
+    T.mesh_root4.assign(d->n_meshes, -1);
+    bool shared = false;  // a node or leaf with two parents has no single ancestor chain: no four-wide walk then
     for (uint32_t i = 0; i < d->n_nodes; i++) {
-        const rt_bvh_node& n = d->nodes[i];
-        const uint32_t ch[2] = {n.left, n.right};
-        for (int c = 0; c < 2; c++) {
-            out[i].child[c] = ch[c];
-            if (ch[c] == RT_REF_END) {  // cannot happen in a tree built by the loader; make the box unhittable
-                for (int k = 0; k < 3; k++) out[i].lo[c][k] = 1e300, out[i].hi[c][k] = -1e300;
-            } else if (ch[c] & RT_REF_LEAF) {
-                const rt_bvh_leaf& lf = d->leaves[ch[c] & ~RT_REF_LEAF];
-                const double v[3][3] = {{lf.O1.x, lf.O1.y, lf.O1.z}, {lf.O2.x, lf.O2.y, lf.O2.z}, {lf.O3.x, lf.O3.y, lf.O3.z}};
-                for (int k = 0; k < 3; k++) {
-                    double lo = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k])), hi = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
-                    double pad = 1e-9 * (1.0 + std::fabs(lo) + std::fabs(hi)) + 1e-7 * (hi - lo);
-                    out[i].lo[c][k] = lo - pad, out[i].hi[c][k] = hi + pad;
+        for (uint32_t c : {d->nodes[i].left, d->nodes[i].right}) {
+            if (c == RT_REF_END) continue;
+            uint32_t& slot = (c & RT_REF_LEAF) ? T.leaf_parent[c & ~RT_REF_LEAF] : T.node_parent[c];
+            shared = shared || slot != RT_REF_END;
+            slot = i;
+        }
+    }
+    for (int mi = 0; mi < d->n_meshes; mi++) {  // roots must not hang under another node either
+        const uint32_t r = d->meshes[mi].root;
+        if (r != RT_REF_END && !(r & RT_REF_LEAF)) shared = shared || T.node_parent[r] != RT_REF_END;
+    }
+    if (shared) return;
+    struct Item {
+        uint32_t bnode, idx4;
+        int level;
+    };
+    for (int mi = 0; mi < d->n_meshes; mi++) {
+        const uint32_t root = d->meshes[mi].root;
+        if (root == RT_REF_END || (root & RT_REF_LEAF)) continue;
+        const size_t first = T.nodes.size();
+        bool usable = true;
+        int levels = 0;
+        std::vector<Item> todo{{root, (uint32_t)first, 1}};
+        T.nodes.push_back(DevNode4{});
+        while (!todo.empty() && usable) {
+            const Item it = todo.back();
+            todo.pop_back();
+            levels = std::max(levels, it.level);
+            uint32_t kids[4];
+            int nk = 0;
+            double plo[3], phi[3];
+            ref_bounds(d, it.bnode, plo, phi);
+            for (uint32_t c : {d->nodes[it.bnode].left, d->nodes[it.bnode].right}) {
+                if (c == RT_REF_END) continue;
+                double clo[3], chi[3];
+                ref_bounds(d, c, clo, chi);
+                for (int k = 0; k < 3; k++) usable = usable && plo[k] <= clo[k] && chi[k] <= phi[k];
+                if (c & RT_REF_LEAF) {
+                    kids[nk++] = c;
+                    continue;
                 }
-            } else {
-                const rt_bvh_node& cn = d->nodes[ch[c]];
-                for (int k = 0; k < 3; k++) out[i].lo[c][k] = cn.bmin[k], out[i].hi[c][k] = cn.bmax[k];
+                for (uint32_t gc : {d->nodes[c].left, d->nodes[c].right}) {
+                    if (gc == RT_REF_END) continue;
+                    double glo[3], ghi[3];
+                    ref_bounds(d, gc, glo, ghi);
+                    for (int k = 0; k < 3; k++) usable = usable && clo[k] <= glo[k] && ghi[k] <= chi[k];
+                    kids[nk++] = gc;
+                }
             }
+            DevNode4 n4;
+            std::memset(&n4, 0, sizeof(n4));
+            for (int c = 0; c < 4; c++) n4.child[c] = RT_REF_END;
+            for (int c = 0; c < nk; c++) {
+                double lo[3], hi[3];
+                ref_bounds(d, kids[c], lo, hi);
+                for (int k = 0; k < 3; k++) {
+                    usable = usable && std::isfinite(lo[k]) && std::isfinite(hi[k]) && std::fabs(lo[k]) < 1e6 && std::fabs(hi[k]) < 1e6;
+                    // a triangle accepted by the double-precision test may lie a rounding error outside its exact bounds
+                    const double pad = (kids[c] & RT_REF_LEAF) ? 1e-9 * (1.0 + std::fabs(lo[k]) + std::fabs(hi[k])) + 1e-7 * (hi[k] - lo[k]) : 0.0;
+                    n4.lo[k][c] = round_down(lo[k] - pad), n4.hi[k][c] = round_up(hi[k] + pad);
+                }
+                if (kids[c] & RT_REF_LEAF) {
+                    n4.child[c] = kids[c];
+                } else {
+                    n4.child[c] = (uint32_t)T.nodes.size();
+                    todo.push_back({kids[c], n4.child[c], it.level + 1});
+                    T.nodes.push_back(DevNode4{});
+                }
+            }
+            T.nodes[it.idx4] = n4;
+        }
+        if (usable && 3 * levels <= RT_STACK && T.nodes.size() < (1u << 30)) {
+            T.mesh_root4[mi] = (int32_t)first;
+        } else {
+            T.nodes.resize(first);
         }
     }
 }
 
-static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g, std::vector<DevGeom>& segs) {
+static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g, std::vector<DevGeom>& segs, const Tree4& T) {
     using namespace hostmath;
     std::memset(&g, 0, sizeof(g));
     g.type = p.type;
@@ -744,7 +889,7 @@ static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g
             }
             g.f[MSH_SCALE] = 3.0 * sc;
             put(g, MSH_BMIN, lo), put(g, MSH_BMAX, hi);
-            g.aux2 = (measured_depth(d, m.root) + 2 <= RT_STACK) ? 1 : 0;
+            g.aux2 = T.mesh_root4[p.u.mesh.mesh] + 1;
             set_ball(g, (lo + hi) * 0.5, 0.5 * hmodule(hi - lo));  // empty mesh: a point ball, never reached
             break;
         }
@@ -761,6 +906,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (s->queue) (void)hipFree(s->queue);
     if (s->counters) (void)hipFree(s->counters);
     if (s->image) (void)hipFree(s->image);
+    if (s->path_buf) (void)hipFree(s->path_buf);
     if (s->tiles) (void)hipFree(s->tiles);
     if (s->prefix) (void)hipFree(s->prefix);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -782,12 +928,12 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     } guard{s};
     HIPCHK(hipGetDevice(&s->device));
 
-    // one slab: lights | geometry | Bezier segments | primitives | primitive extras | nodes | leaves | texels, one copy
+    // one slab: lights | geometry | Bezier segments | primitives | primitive extras | nodes | four-wide nodes | parents | leaves | texels, one copy
     std::vector<DevPrimX> px((size_t)d->n_primitives);
     std::vector<DevGeom> geom((size_t)d->n_primitives), segs;
     std::vector<uint32_t> tex_off((size_t)d->n_textures);
-    std::vector<DevNode2> nodes2;
-    build_nodes2(d, nodes2);
+    Tree4 T;
+    build_tree4(d, T);
     size_t texel_bytes = 0;
     for (int i = 0; i < d->n_textures; i++) {
         tex_off[i] = (uint32_t)texel_bytes;
@@ -802,7 +948,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             const rt_texture& t = d->textures[p.material.texture];
             x.tex_w = t.width, x.tex_h = t.height, x.tex_off = tex_off[p.material.texture];
         }
-        build_geom(d, p, geom[i], segs);
+        build_geom(d, p, geom[i], segs, T);
     }
     size_t off_l = 0;
     size_t off_g = align_up(off_l + sizeof(rt_light) * d->n_lights, 256);
@@ -811,7 +957,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     size_t off_x = align_up(off_p + sizeof(rt_primitive) * d->n_primitives, 256);
     size_t off_n = align_up(off_x + sizeof(DevPrimX) * d->n_primitives, 256);
     size_t off_n2 = align_up(off_n + sizeof(rt_bvh_node) * (size_t)d->n_nodes, 256);
-    size_t off_f = align_up(off_n2 + sizeof(DevNode2) * (size_t)d->n_nodes, 256);
+    size_t off_np = align_up(off_n2 + sizeof(DevNode4) * T.nodes.size(), 256);
+    size_t off_lp = align_up(off_np + sizeof(uint32_t) * (size_t)d->n_nodes, 256);
+    size_t off_f = align_up(off_lp + sizeof(uint32_t) * (size_t)d->n_leaves, 256);
     size_t off_t = align_up(off_f + sizeof(rt_bvh_leaf) * (size_t)d->n_leaves, 256);
     s->slab_bytes = align_up(off_t + texel_bytes, 256) + 256;
     std::vector<uint8_t> host(s->slab_bytes, 0);
@@ -821,7 +969,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (d->n_primitives) std::memcpy(&host[off_p], d->primitives, sizeof(rt_primitive) * d->n_primitives);
     if (d->n_primitives) std::memcpy(&host[off_x], px.data(), sizeof(DevPrimX) * d->n_primitives);
     if (d->n_nodes) std::memcpy(&host[off_n], d->nodes, sizeof(rt_bvh_node) * (size_t)d->n_nodes);
-    if (d->n_nodes) std::memcpy(&host[off_n2], nodes2.data(), sizeof(DevNode2) * (size_t)d->n_nodes);
+    if (!T.nodes.empty()) std::memcpy(&host[off_n2], T.nodes.data(), sizeof(DevNode4) * T.nodes.size());
+    if (d->n_nodes) std::memcpy(&host[off_np], T.node_parent.data(), sizeof(uint32_t) * (size_t)d->n_nodes);
+    if (d->n_leaves) std::memcpy(&host[off_lp], T.leaf_parent.data(), sizeof(uint32_t) * (size_t)d->n_leaves);
     if (d->n_leaves) std::memcpy(&host[off_f], d->leaves, sizeof(rt_bvh_leaf) * (size_t)d->n_leaves);
     for (int i = 0; i < d->n_textures; i++)
         std::memcpy(&host[off_t + tex_off[i]], d->textures[i].rgb, (size_t)d->textures[i].width * d->textures[i].height * 3);
@@ -839,18 +989,23 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->desc_cam_w = d->camera.W, s->desc_cam_h = d->camera.H;
     v.shade_n = (int)(16 * d->camera.shade_quality);
     v.n_lights = d->n_lights, v.n_prims = d->n_primitives;
+    v.mesh_mask = 0;
+    for (int i = 0; i < d->n_primitives && i < 64; i++)
+        if (d->primitives[i].type == RT_PRIM_MESH) v.mesh_mask |= 1ull << i;
     v.lights = (const rt_light*)(base + off_l);
     v.geom = (const DevGeom*)(base + off_g);
     v.segs = (const DevGeom*)(base + off_s);
     v.prims = (const rt_primitive*)(base + off_p);
     v.primx = (const DevPrimX*)(base + off_x);
     v.nodes = (const rt_bvh_node*)(base + off_n);
-    v.nodes2 = (const DevNode2*)(base + off_n2);
+    v.nodes4 = (const DevNode4*)(base + off_n2);
+    v.node_parent = (const uint32_t*)(base + off_np);
+    v.leaf_parent = (const uint32_t*)(base + off_lp);
     v.leaves = (const rt_bvh_leaf*)(base + off_f);
     v.texels = base + off_t;
 
     HIPCHK(hipMalloc(&s->queue, 256));
-    HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * CTR_ALL));
+    HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * (CTR_ALL + 16)));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
     hipDeviceProp_t prop;
@@ -882,18 +1037,33 @@ static int check_common(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
 // Render the given tiles into `dst` (device image).  Fills kernel time and counters.
 static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, const std::vector<Tile>& tiles,
                         uint8_t* dst, rt_stats* stats) {
-    const int ppt = st->spp >= 64 ? 1 : 64 / st->spp;
     std::vector<uint32_t> prefix(tiles.size() + 1, 0);
-    uint64_t pixels = 0, tasks = 0;
+    uint64_t pixels = 0, blocks = 0;
     for (size_t i = 0; i < tiles.size(); i++) {
         const Tile& t = tiles[i];
-        uint64_t slots = (uint64_t)((t.w + 7) / 8) * ((t.h + 7) / 8) * 64;
-        prefix[i] = (uint32_t)tasks;
-        tasks += (slots + ppt - 1) / ppt;
+        prefix[i] = (uint32_t)blocks;
+        blocks += (uint64_t)((t.w + 7) / 8) * ((t.h + 7) / 8);
         pixels += (uint64_t)t.w * t.h;
-        if (tasks >= (1ull << 31)) return rt_fail(RT_ERR_LIMIT, "too many tasks in one call");
+        if (blocks >= (1ull << 24)) return rt_fail(RT_ERR_LIMIT, "too many pixels in one call");
     }
-    prefix[tiles.size()] = (uint32_t)tasks;
+    prefix[tiles.size()] = (uint32_t)blocks;
+    const bool strict = (st->flags & RT_F_STRICT_TRAVERSAL) != 0;
+    const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
+    const uint64_t waves = (uint64_t)s->cus * bpc * 4;
+    // Slots per task: as many as the wave's colour buffer holds (long tasks keep the lanes refilled), fewer
+    // if the image is too small to give every wave several tasks, never fewer than one wave's worth of paths.
+    int s_max = 64;
+    while (s_max > 1 && (uint64_t)s_max * st->spp > RT_BATCH_PATHS) s_max >>= 1;
+    int s_min = 1;
+    while (s_min < 64 && s_min * st->spp < 64) s_min <<= 1;
+    if (s_min > s_max) s_min = s_max;
+    int sA = s_max;
+    while (sA > s_min && blocks * (uint64_t)(64 / sA) < 4 * waves) sA >>= 1;
+    const int sB = std::max(s_min, sA / 4), sC = std::max(s_min, sA / 16);
+    const uint32_t bA = (uint32_t)(blocks * 80 / 100), bB = (uint32_t)(blocks * 95 / 100);
+    const uint64_t tA = (uint64_t)bA * (64 / sA), tB = tA + (uint64_t)(bB - bA) * (64 / sB);
+    const uint64_t tasks = tB + (blocks - bB) * (uint64_t)(64 / sC);
+    if (tasks >= (1ull << 31)) return rt_fail(RT_ERR_LIMIT, "too many tasks in one call");
     if (tiles.size() > s->tiles_cap) {
         if (s->tiles) (void)hipFree(s->tiles);
         if (s->prefix) (void)hipFree(s->prefix);
@@ -906,7 +1076,7 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     HIPCHK(hipMemcpyAsync(s->tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(s->prefix, prefix.data(), prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
-    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * CTR_ALL, g_stream));
+    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));
 
     RenderParams P;
     P.sc = s->dev;
@@ -915,15 +1085,23 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     P.tex_w = tex_w, P.tex_h = tex_h, P.spp = st->spp, P.dof = st->dof_enabled ? 1 : 0;
     P.focal = st->focal_distance, P.aperture = st->aperture;
     P.k0 = (uint32_t)st->seed, P.k1 = (uint32_t)(st->seed >> 32), P.flags = st->flags;
-    P.n_tiles = (int)tiles.size(), P.ppt = ppt, P.n_tasks = (uint32_t)tasks;
+    P.n_tiles = (int)tiles.size(), P.n_tasks = (uint32_t)tasks;
+    P.bA = bA, P.bB = bB, P.tA = (uint32_t)tA, P.tB = (uint32_t)tB, P.sA = sA, P.sB = sB, P.sC = sC;
     P.tiles = s->tiles, P.tile_prefix = s->prefix, P.queue = s->queue, P.out = dst, P.counters = s->counters;
 
-    const bool strict = (st->flags & RT_F_STRICT_TRAVERSAL) != 0;
-    const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
     uint64_t want_blocks = (tasks + 3) / 4;
     uint64_t grid = (uint64_t)s->cus * bpc;
     if (grid > want_blocks) grid = want_blocks;
     if (grid < 1) grid = 1;
+    // colours of finished paths, one buffer per wave of the grid
+    const size_t buf_bytes = (size_t)grid * 4 * RT_BATCH_PATHS * 3 * sizeof(double);
+    if (s->path_buf_bytes < buf_bytes) {
+        if (s->path_buf) (void)hipFree(s->path_buf);
+        s->path_buf = nullptr, s->path_buf_bytes = 0;
+        HIPCHK(hipMalloc(&s->path_buf, buf_bytes));
+        s->path_buf_bytes = buf_bytes;
+    }
+    P.path_buf = s->path_buf;
     HIPCHK(hipEventRecord(s->ev0, g_stream));
     if (tasks > 0) {
         if (strict) hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(256), 0, g_stream, P);
@@ -931,13 +1109,27 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s->ev1, g_stream));
-    unsigned long long c[CTR_ALL];
+    unsigned long long c[CTR_ALL + 16];
     HIPCHK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
 #ifdef RT_UTIL_COUNTERS
     std::fprintf(stderr, "[util] shadow lanes used %.1f%% (%llu of %llu slots), closest-hit lanes used %.1f%% (%llu of %llu slots)\n",
                  100.0 * c[CTR_U_SHADOW_ITEMS] / (double)(c[CTR_U_SHADOW_SLOTS] ? c[CTR_U_SHADOW_SLOTS] : 1), c[CTR_U_SHADOW_ITEMS], c[CTR_U_SHADOW_SLOTS],
                  100.0 * c[CTR_U_TRACE_ACTIVE] / (double)(c[CTR_U_TRACE_SLOTS] ? c[CTR_U_TRACE_SLOTS] : 1), c[CTR_U_TRACE_ACTIVE], c[CTR_U_TRACE_SLOTS]);
+    static const char* const probe_name[6] = {"shadow mesh walks", "closest mesh walks", "shadow interior steps", "shadow leaf steps",
+                                              "closest interior steps", "closest leaf steps"};
+    static const char* const sect[PF_COUNT] = {"task setup / resolve", "frame stack", "closest: analytic prims", "closest: mesh walk", "shade setup + texture",
+                                               "light candidates", "chunk shuffles + counts", "rng + light sample", "shadow: analytic prims", "shadow: mesh walk",
+                                               "shade math"};
+    unsigned long long tot = 0;
+    for (int k = 0; k < PF_COUNT; k++) tot += c[CTR_ALL + k];
+    for (int k = 0; k < PF_COUNT; k++)
+        std::fprintf(stderr, "[time] %-26s %5.1f%%\n", sect[k], 100.0 * c[CTR_ALL + k] / (double)(tot ? tot : 1));
+    for (int k = 0; k < 6; k++) {
+        const unsigned long long lanes = c[CTR_U_PROBES + 2 * k], slots = c[CTR_U_PROBES + 2 * k + 1];
+        std::fprintf(stderr, "[util] %-24s lanes %.1f%% (%llu lane executions, %llu wave executions)\n", probe_name[k],
+                     100.0 * lanes / (double)(slots ? slots : 1), lanes, slots / 64);
+    }
 #endif
     if (stats) {
         float ms = 0;

@@ -21,7 +21,7 @@ struct DevGeom {  // 192 bytes
     int32_t type;
     uint32_t aux0;  // mesh: BVH root ref; bezier: first segment in DevScene::segs
     int32_t aux1;   // bezier: number of segments (two more records follow them: curve frame, curve coefficients); mesh: mesh index
-    int32_t aux2;   // mesh: 1 if the paired-box tree + LDS stack walk may be used (depth fits the stack)
+    int32_t aux2;   // mesh: 1 + index of its root DevNode4 if the four-wide walk may be used, else 0
     double f[22];
 };
 // field map of DevGeom::f
@@ -35,16 +35,18 @@ enum {
     BND_C = 17, BND_R = 20                                              // bounding ball (cylinder, bezier, segments)
 };
 
-// Interior BVH node for the pruned walk: the boxes of BOTH children next to their refs, so one
-// fetch decides both descents and the nearer child can be entered first.  Same tree, same boxes
-// as rt_bvh_node (interior children carry the exact box the reference tests, CR/Collision_Mesh.cu:75);
-// a leaf child carries its triangle's bounds, slightly inflated, as a pre-test the reference does not
-// have - it can only discard triangles the ray misses.
-#define RT_STACK 24  // per-lane traversal stack entries (LDS); meshes deeper than RT_STACK - 2 use the stackless walk
-struct DevNode2 {    // 128 bytes
-    double lo[2][3], hi[2][3];
-    uint32_t child[2];
-    uint32_t pad_[6];
+// Node of the pruned walk: the binary tree of the reference collapsed two levels at a time, so a
+// node holds up to four children (the grandchildren of a binary node; a leaf child of the binary
+// node stays a child) with their boxes in single precision, rounded outward.  The boxes only steer
+// the walk - they decide which triangles get tested, never a hit: triangles are tested in double
+// with the reference's arithmetic, and a hit is kept only if the reference's own double-precision
+// box tests would have led to that triangle (see mesh_walk4).  Child refs: node4 index, or
+// RT_REF_LEAF | leaf index, or RT_REF_END for an unused slot.
+#define RT_STACK 32  // per-lane traversal stack entries (LDS); a mesh whose collapsed tree needs more uses the stackless walk
+struct DevNode4 {    // 128 bytes
+    float lo[3][4], hi[3][4];  // [axis][child]
+    uint32_t child[4];
+    uint32_t pad_[4];
 };
 
 // Per-primitive shading extras (indexed per lane at a hit).
@@ -57,13 +59,16 @@ struct DevPrimX {
 struct DevScene {
     d3 bg_top, bg_bottom, camO, camN, camDx, camDy;
     int32_t cam_w, cam_h, shade_n, n_lights, n_prims;
+    unsigned long long mesh_mask;  // bit j set: primitive j (< 64) is a mesh
     const rt_light* lights;        // read as RT_CONST
     const DevGeom* geom;           // read as RT_CONST, one per primitive
     const DevGeom* segs;           // read as RT_CONST, Bezier cylinder segments
     const rt_primitive* prims;     // materials + texture frames, per-lane lookups
     const DevPrimX* primx;
     const rt_bvh_node* nodes;
-    const DevNode2* nodes2;        // same indices as `nodes`
+    const DevNode4* nodes4;        // collapsed tree of the pruned walk
+    const uint32_t* node_parent;   // per rt_bvh_node: parent node (RT_REF_END at a root)
+    const uint32_t* leaf_parent;   // per rt_bvh_leaf: parent node (RT_REF_END if the leaf is a root)
     const rt_bvh_leaf* leaves;
     const uint8_t* texels;
 };
@@ -83,8 +88,33 @@ struct Counters {  // per-lane work counters, flushed once per wave
     uint32_t rays_secondary, rays_shadow, nodes, tris, shaded, texfetch;
 #ifdef RT_UTIL_COUNTERS
     uint32_t u_shadow_slots, u_shadow_items, u_trace_slots, u_trace_active;
+    uint32_t u[12];  // pairs (lane executions, 64 x wave executions): shadow mesh calls, closest mesh calls, then interior / leaf steps of each
+    unsigned long long* prof;  // this wave's LDS record: [0] = time of the last lap, [1 + section] = cycles spent per section
 #endif
 };
+// sections of the per-wave time profile (util builds)
+enum { PF_TASK = 0, PF_FRAME, PF_CLOSEST_PRIMS, PF_CLOSEST_MESH, PF_SHADE_SETUP, PF_CAND, PF_CHUNK_SHFL, PF_RNG, PF_SH_PRIMS, PF_SH_MESH,
+       PF_SHADE_MATH, PF_COUNT };
+// lane-utilisation probe: counts this lane, and 64 slots once per wave-level execution
+#ifdef RT_UTIL_COUNTERS
+#define RT_PROBE(ctr, k)                                                                            \
+    do {                                                                                            \
+        (ctr).u[2 * (k)]++;                                                                         \
+        if (lane_id() == (int)__ffsll((long long)__ballot(true)) - 1) (ctr).u[2 * (k) + 1] += 64u;  \
+    } while (0)
+// RT_LAP(ctr, s): the time since the previous lap of this wave is charged to section s
+#define RT_LAP(ctr, s)                                                                              \
+    do {                                                                                            \
+        const unsigned long long now_ = __builtin_readcyclecounter();                               \
+        if (lane_id() == (int)__ffsll((long long)__ballot(true)) - 1) {                             \
+            (ctr).prof[1 + (s)] += now_ - (ctr).prof[0];                                            \
+            (ctr).prof[0] = now_;                                                                   \
+        }                                                                                           \
+    } while (0)
+#else
+#define RT_PROBE(ctr, k) do { } while (0)
+#define RT_LAP(ctr, s) do { } while (0)
+#endif
 
 DEV d3 G3(const DevGeom RT_CONST& g, int i) { return d3{g.f[i], g.f[i + 1], g.f[i + 2]}; }
 
@@ -451,76 +481,121 @@ DEV MeshResult mesh_walk(const DevScene& sc, uint32_t root, d3 o, d3 d, double t
     return res;
 }
 
-// Pruned walk over the paired-box tree with a per-lane stack in LDS (`stk` points at this lane's
-// column; entry k lives at stk[k * 64]).  Children are entered nearest first, the other one is
-// pushed.  It tests a subset of the triangles the reference-order walk tests - never one more,
-// and never drops one that could be the answer:
-//   * an interior child is entered only if the reference's own slab test passes (same arithmetic),
-//     it is not wholly behind the origin and not wholly beyond t_limit (both relaxed by `margin`);
-//   * a leaf child is dropped only if the ray misses its inflated bounds or they lie beyond t_limit;
+// Would the reference's depth-first walk (CR/Collision_Mesh.cu:65-80) have reached this leaf?  It does
+// iff the slab test of every ancestor passes; same arithmetic as mesh_walk<true, ...>.
+DEV bool reference_reaches_leaf(const DevScene& sc, uint32_t leaf_index, d3 o, d3 inv) {
+    uint32_t n = sc.leaf_parent[leaf_index];
+    while (n != RT_REF_END) {
+        const rt_bvh_node& nd = sc.nodes[n];
+        double t0x = (nd.bmin[0] - o.x) * inv.x, t1x = (nd.bmax[0] - o.x) * inv.x;
+        double t0y = (nd.bmin[1] - o.y) * inv.y, t1y = (nd.bmax[1] - o.y) * inv.y;
+        double t0z = (nd.bmin[2] - o.z) * inv.z, t1z = (nd.bmax[2] - o.z) * inv.z;
+        double tminmax = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
+        double tmaxmin = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
+        if (!(tminmax <= tmaxmin)) return false;
+        n = sc.node_parent[n];
+    }
+    return true;
+}
+
+// Pruned walk over the four-wide tree with a per-lane stack in LDS (`stk` points at this lane's
+// column; entry k lives at stk[k * 64]).  It returns exactly what the reference-order walk returns:
+//   * the single-precision boxes are supersets of the reference's boxes and every comparison is
+//     relaxed by M, a bound on the rounding error of the slab distances of this ray, so a child is
+//     skipped only if the ray misses the reference's box, or the box lies wholly behind the origin,
+//     or wholly beyond t_limit - no triangle the reference would accept within t_limit is lost;
+//   * the superset may reach a triangle the reference never tests, because one of its own box tests
+//     fails by a rounding error.  The host has checked that every box of this mesh contains the boxes
+//     below it, so a hit point well inside its triangle's bounds is well inside every ancestor box
+//     and those tests pass; only a hit within a hair of its triangle's bounds re-runs the ancestors'
+//     tests in double (reference_reaches_leaf);
 //   * ties go to the smaller pre-order index, which is the leaf the reference meets first.
+// Rays whose slab distances do not fit single precision take the stackless double-precision walk.
 template <bool ANYHIT>
-DEV MeshResult mesh_walk_fast(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk) {
-    MeshResult res{RT_BIG_DIST, RT_REF_END};
-    uint32_t res_pre = 0xFFFFFFFFu;
-    const double t_exact = t_limit;
+DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk) {
     const d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    double m = 0.0;
-    if (fabs(inv.x) < 1e300) m = fmax(m, fabs(inv.x));
-    if (fabs(inv.y) < 1e300) m = fmax(m, fabs(inv.y));
-    if (fabs(inv.z) < 1e300) m = fmax(m, fabs(inv.z));
-    const double margin = 1e-13 * (g.f[MSH_SCALE] + fabs(o.x) + fabs(o.y) + fabs(o.z)) * m;
-    t_limit = t_limit + margin + 1e-9 * fabs(t_limit);
-    uint32_t ref = g.aux0;
-    if (ref == RT_REF_END) return res;
-    if (!(ref & RT_REF_LEAF)) {  // root box (CR/Renderer_CUDA.cpp:234-235: the vertex bounds)
+    const double S = g.f[MSH_SCALE];
+    const double mm = fmax(fmax((S + fabs(o.x)) * fabs(inv.x), (S + fabs(o.y)) * fabs(inv.y)), (S + fabs(o.z)) * fabs(inv.z));
+    if (!(mm < 1e30) || !(fabs(inv.x) < 1e30) || !(fabs(inv.y) < 1e30) || !(fabs(inv.z) < 1e30)) {
+        uint32_t dummy = 0;
+        return mesh_walk<false, ANYHIT, false>(sc, g.aux0, o, d, t_limit, S, ctr, nullptr, 0, dummy, 0);
+    }
+    MeshResult res{RT_BIG_DIST, RT_REF_END};
+    {   // root box (CR/Renderer_CUDA.cpp:234-235: the vertex bounds) from the scalar registers: the reference's
+        // own test, plus "wholly beyond t_limit" and "wholly behind", relaxed by the rounding error of the distances
         ctr.nodes++;
+        const double margin = 1e-13 * mm;
         double t0x = (g.f[MSH_BMIN] - o.x) * inv.x, t1x = (g.f[MSH_BMAX] - o.x) * inv.x;
         double t0y = (g.f[MSH_BMIN + 1] - o.y) * inv.y, t1y = (g.f[MSH_BMAX + 1] - o.y) * inv.y;
         double t0z = (g.f[MSH_BMIN + 2] - o.z) * inv.z, t1z = (g.f[MSH_BMAX + 2] - o.z) * inv.z;
         double tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
         double tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
-        if (!(tn <= tf) || tn > t_limit || tf < -margin) return res;
+        if (!(tn <= tf) || tn > t_limit + margin + 1e-9 * fabs(t_limit) || tf < -margin) return res;
     }
+    uint32_t res_pre = 0xFFFFFFFFu;
+    const double t_exact = t_limit;
+    // slab distance of plane p on axis k: fma(p, ik, ck); |error| <= 2^-22 (S + |o_k|) |1/d_k| <= M
+    const float ix = (float)inv.x, iy = (float)inv.y, iz = (float)inv.z;
+    const float cx = (float)(-(o.x * inv.x)), cy = (float)(-(o.y * inv.y)), cz = (float)(-(o.z * inv.z));
+    const float M = (float)(mm * 2.4e-7) * 1.000001f + 1e-30f;
+    float tl = (float)t_limit;  // +inf if beyond single precision
+    tl = tl + fabsf(tl) * 2.4e-7f;
+    RT_PROBE(ctr, ANYHIT ? 0 : 1);
+    uint32_t ref = (uint32_t)(g.aux2 - 1);
     int sp = 0;
     for (;;) {
         while (!(ref & RT_REF_LEAF)) {
-            const DevNode2& n = sc.nodes2[ref];
+            const DevNode4& n = sc.nodes4[ref];
             ctr.nodes++;
-            bool ok[2];
-            double tn[2];
+            RT_PROBE(ctr, ANYHIT ? 2 : 4);
+            float key[4];
+            uint32_t rf[4];
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                double t0x = (n.lo[c][0] - o.x) * inv.x, t1x = (n.hi[c][0] - o.x) * inv.x;
-                double t0y = (n.lo[c][1] - o.y) * inv.y, t1y = (n.hi[c][1] - o.y) * inv.y;
-                double t0z = (n.lo[c][2] - o.z) * inv.z, t1z = (n.hi[c][2] - o.z) * inv.z;
-                double a = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
-                double b = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
-                const bool leafc = (n.child[c] & RT_REF_LEAF) != 0;
-                bool e = leafc ? !(a > b + margin) : (a <= b);
-                ok[c] = e && !(a > t_limit) && !(b < -margin);
-                tn[c] = a;
+            for (int c = 0; c < 4; c++) {
+                const float t0x = __builtin_fmaf(n.lo[0][c], ix, cx), t1x = __builtin_fmaf(n.hi[0][c], ix, cx);
+                const float t0y = __builtin_fmaf(n.lo[1][c], iy, cy), t1y = __builtin_fmaf(n.hi[1][c], iy, cy);
+                const float t0z = __builtin_fmaf(n.lo[2][c], iz, cz), t1z = __builtin_fmaf(n.hi[2][c], iz, cz);
+                const float a = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)) - M;
+                const float b = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) + M;
+                rf[c] = n.child[c];
+                const bool ok = rf[c] != RT_REF_END && a <= b && !(a > tl) && !(b < 0.0f);
+                key[c] = ok ? a : __builtin_inff();
             }
-            if (ok[0] && ok[1]) {
-                const int near = tn[1] < tn[0] ? 1 : 0;
-                if (sp < RT_STACK) stk[sp * 64] = n.child[near ^ 1], sp++;
-                ref = n.child[near];
-            } else if (ok[0]) {
-                ref = n.child[0];
-            } else if (ok[1]) {
-                ref = n.child[1];
-            } else if (sp > 0) {
-                ref = stk[(--sp) * 64];
+            if (!ANYHIT) {  // nearest first
+#define RT_CE(i, j)                                                  \
+    {                                                                \
+        const bool sw = key[j] < key[i];                             \
+        const float ka = sw ? key[j] : key[i], kb = sw ? key[i] : key[j]; \
+        const uint32_t ra = sw ? rf[j] : rf[i], rb = sw ? rf[i] : rf[j];  \
+        key[i] = ka, key[j] = kb, rf[i] = ra, rf[j] = rb;            \
+    }
+                RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+                if (key[3] < __builtin_inff() && sp < RT_STACK) stk[sp * 64] = rf[3], sp++;
+                if (key[2] < __builtin_inff() && sp < RT_STACK) stk[sp * 64] = rf[2], sp++;
+                if (key[1] < __builtin_inff() && sp < RT_STACK) stk[sp * 64] = rf[1], sp++;
+                if (key[0] < __builtin_inff()) ref = rf[0];
+                else ref = sp > 0 ? stk[(--sp) * 64] : RT_REF_END;
             } else {
-                ref = RT_REF_END;
+                uint32_t next = RT_REF_END;
+                bool have = false;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (key[c] < __builtin_inff()) {
+                        if (!have) next = rf[c], have = true;
+                        else if (sp < RT_STACK) stk[sp * 64] = rf[c], sp++;
+                    }
+                }
+                ref = have ? next : (sp > 0 ? stk[(--sp) * 64] : RT_REF_END);
             }
         }
         if (ref == RT_REF_END) break;
-        const rt_bvh_leaf& lf = sc.leaves[ref & ~RT_REF_LEAF];
+        const uint32_t here = ref, leaf_index = ref & ~RT_REF_LEAF;
+        const rt_bvh_leaf& lf = sc.leaves[leaf_index];
         ctr.tris++;
-        const uint32_t here = ref;
+        RT_PROBE(ctr, ANYHIT ? 3 : 5);
         ref = sp > 0 ? stk[(--sp) * 64] : RT_REF_END;
-        d3 O1 = D3(lf.O1), e1 = D3(lf.O2) - O1, e2 = D3(lf.O3) - O1;
+        const d3 O1 = D3(lf.O1), O2 = D3(lf.O2), O3 = D3(lf.O3), e1 = O2 - O1, e2 = O3 - O1;
         d3 p = cross(d, e2);
         double det = dot(e1, p);
         if (fabs(det) < RT_EPS) continue;
@@ -533,17 +608,22 @@ DEV MeshResult mesh_walk_fast(const DevScene& sc, const DevGeom RT_CONST& g, d3 
         if (v < 0.0 || u + v > 1.0) continue;
         double t0 = dot(e2, q) * idet;
         if (t0 <= RT_EPS) continue;
-        if (t0 < res.t || (t0 == res.t && lf.preorder < res_pre)) {
-            res.t = t0;
-            res.leaf = here;
-            res_pre = lf.preorder;
-            if (ANYHIT) {
-                if (t_exact - t0 > RT_EPS) break;
-            } else {
-                double lim = t0 + margin + 1e-9 * fabs(t0);
-                if (lim < t_limit) t_limit = lim;
-            }
+        const bool wanted = ANYHIT ? (t_exact - t0 > RT_EPS) : (t0 < res.t || (t0 == res.t && lf.preorder < res_pre));
+        if (!wanted) continue;
+        {   // the reference must have reached this leaf
+            const d3 P = o + d * t0;
+            const double eps = 1e-9 * (S + fabs(o.x) + fabs(o.y) + fabs(o.z) + fabs(P.x) + fabs(P.y) + fabs(P.z));
+            const bool inside = P.x - fmin(O1.x, fmin(O2.x, O3.x)) > eps && fmax(O1.x, fmax(O2.x, O3.x)) - P.x > eps &&
+                                P.y - fmin(O1.y, fmin(O2.y, O3.y)) > eps && fmax(O1.y, fmax(O2.y, O3.y)) - P.y > eps &&
+                                P.z - fmin(O1.z, fmin(O2.z, O3.z)) > eps && fmax(O1.z, fmax(O2.z, O3.z)) - P.z > eps;
+            if (!inside && !reference_reaches_leaf(sc, leaf_index, o, inv)) continue;
         }
+        res.t = t0;
+        res.leaf = here;
+        res_pre = lf.preorder;
+        if (ANYHIT) break;
+        tl = (float)t0;
+        tl = tl + fabsf(tl) * 2.4e-7f;
     }
     return res;
 }
@@ -592,12 +672,14 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
                 break;
             case RT_PRIM_TRIANGLE: t = triangle_hit<true>(g, o, dm, tmp); break;
             case RT_PRIM_MESH: {
+                RT_LAP(ctr, PF_CLOSEST_PRIMS);
                 MeshResult r = (!STRICT && g.aux2 && stk)
-                                   ? mesh_walk_fast<false>(sc, g, o, dm, lim, ctr, stk)
+                                   ? mesh_walk4<false>(sc, g, o, dm, lim, ctr, stk)
                                    : mesh_walk<STRICT, false, LOG>(sc, g.aux0, o, dm, lim, g.f[MSH_SCALE], ctr, log, log_cap, log_n,
                                                                    (uint32_t)g.aux1 << 24);
                 t = r.t;
                 if (t < RT_BIG_DIST) mesh_fill_hit(sc, r.leaf, o, dm, t, tmp);
+                RT_LAP(ctr, PF_CLOSEST_MESH);
                 break;
             }
             default: break;
@@ -729,8 +811,10 @@ DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int c
                 break;
             case RT_PRIM_TRIANGLE: t = triangle_hit<false>(g, C, dm, tmp); break;
             case RT_PRIM_MESH:
-                t = (!STRICT && g.aux2 && stk) ? mesh_walk_fast<true>(sc, g, C, dm, dist, ctr, stk).t
+                RT_LAP(ctr, PF_SH_PRIMS);
+                t = (!STRICT && g.aux2 && stk) ? mesh_walk4<true>(sc, g, C, dm, dist, ctr, stk).t
                                                : mesh_walk<STRICT, true, false>(sc, g.aux0, C, dm, dist, g.f[MSH_SCALE], ctr, nullptr, 0, dummy_n, 0).t;
+                RT_LAP(ctr, PF_SH_MESH);
                 break;
             default: break;
         }
