@@ -16,6 +16,7 @@
 //     sum does not depend on which lane traced which ray.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -28,6 +29,7 @@
 #include "rt_trace.hpp"
 
 static_assert(sizeof(rt_bvh_node) == 64 && sizeof(rt_bvh_leaf) == 96, "BVH record sizes are part of the ABI");
+static_assert(RT_SPEC_POWER == 20, "the specular power is expanded by hand in diffusion_coop");
 static_assert(sizeof(DevNode4) == 128 && sizeof(DevGeom) == 192, "device record sizes");
 static_assert(sizeof(rt_primitive) == 408 && sizeof(rt_light) == 112 && sizeof(rt_scene_desc) == 256 && sizeof(rt_settings) == 40 &&
                   sizeof(rt_stats) == 80,
@@ -59,7 +61,7 @@ struct RenderParams {
     unsigned long long* counters;
 };
 #ifndef RT_BATCH_PATHS
-#define RT_BATCH_PATHS 2048  // paths one wave keeps in flight + waiting in one task round
+#define RT_BATCH_PATHS 256  // paths of one task round: in flight (one per lane) or waiting for a lane
 #endif
 
 enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT,
@@ -100,9 +102,11 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
     const DevScene& sc = P.sc;
     const int lane = lane_id();
     d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
+    double m_diff = 0.0, m_spec = 0.0;
     if (need) {
         const rt_material& m = sc.prims[h.prim].material;
         color = D3(m.color);
+        m_diff = m.diff, m_spec = m.spec;
         if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, h, ctr));
         ctr.shaded++;
     }
@@ -119,10 +123,13 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
         unsigned long long cand = ~0ull;
         bool work = need;
         int cnt = 0;
-        if (need) ctr.rays_shadow += (uint32_t)n_l;
+        double dt = 0.0;  // N.L of CR/Scene_Material.cu:50-51
+        if (need) {
+            ctr.rays_shadow += (uint32_t)n_l;
+            dt = dot(unit(d3{L.O.x, L.O.y, L.O.z} - h.C), h.N);
+        }
         if (!STRICT && need) {
-            const d3 R = unit(d3{L.O.x, L.O.y, L.O.z} - h.C);
-            if (!(dot(R, h.N) > RT_EPS)) {
+            if (!(dt > RT_EPS)) {
                 work = false;
             } else {
                 cand = light_candidates(sc, P.flags, h.C, L);
@@ -140,6 +147,7 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
         const int my_rank = heavy ? rank_in(hmask) : work ? nheavy + rank_in(lmask) : nwork + rank_in(~wmask);
         const int owner_tbl = __builtin_amdgcn_ds_permute(my_rank << 2, lane);  // lane r learns which lane owns slot r
         const int total = nwork * n_l;
+        const float inv_nl = 1.0f / (float)n_l;
         for (int base = 0; base < total; base += 64) {
             const int item = base + lane;
             const bool act = item < total;
@@ -147,7 +155,11 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
             ctr.u_shadow_slots++;
             ctr.u_shadow_items += act ? 1u : 0u;
 #endif
-            const int r = act ? item / n_l : 0;
+            // r = item / n_l (item < 2^22): estimate in single precision, then fix the estimate by one
+            int r = (int)((float)item * inv_nl);
+            if ((r + 1) * n_l <= item) r++;
+            if (r * n_l > item) r--;
+            if (!act) r = 0;
             const int si = item - r * n_l;
             const int owner = __shfl(owner_tbl, r, 64);
             const d3 C = shfl_d3(h.C, owner);
@@ -183,22 +195,19 @@ DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need,
             }
         }
         RT_LAP(ctr, PF_CHUNK_SHFL);
-        if (need) {
+        if (need && dt > RT_EPS) {
             double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
             if (!(shade < RT_EPS)) {
-                const rt_material& m = sc.prims[h.prim].material;
-                d3 R = unit(d3{L.O.x, L.O.y, L.O.z} - h.C);
                 const d3 Lc = d3{L.color.x, L.color.y, L.color.z};
-                double dt = dot(R, h.N);
-                if (dt > RT_EPS) {
-                    if (m.diff > RT_EPS) {
-                        double diff = m.diff * dt * shade;
-                        ret = ret + mulv(color, Lc) * diff;
-                    }
-                    if (m.spec > RT_EPS) {
-                        double spec = m.spec * pow(dt, (double)RT_SPEC_POWER) * shade;
-                        ret = ret + mulv(color, Lc) * spec;
-                    }
+                if (m_diff > RT_EPS) {
+                    double diff = m_diff * dt * shade;
+                    ret = ret + mulv(color, Lc) * diff;
+                }
+                if (m_spec > RT_EPS) {
+                    // pow(N.L, 20) of CR/Scene_Material.cu:60 by squaring (a few ulp from libm's, far below one colour level)
+                    const double p2 = dt * dt, p4 = p2 * p2, p5 = p4 * dt, p10 = p5 * p5;
+                    double spec = m_spec * (p10 * p10) * shade;
+                    ret = ret + mulv(color, Lc) * spec;
                 }
             }
         }
@@ -695,9 +704,89 @@ static void ref_bounds(const rt_scene_desc* d, uint32_t ref, double lo[3], doubl
     }
 }
 
-// Collapse each mesh's binary tree two levels at a time.  A mesh keeps the four-wide walk only if
-// every box is finite, of moderate size and contains the boxes directly below it (the walk's argument
-// for keeping a hit relies on that nesting) and the collapsed tree fits the traversal stack.
+// ---- the walk's own tree -----------------------------------------------------------------------
+// The pruned walk does not have to follow the reference's tree (a median split on cycling axes,
+// CR/Renderer_CUDA.cpp:183-236): any structure that never loses a triangle the ray can hit will do,
+// because a hit is accepted only after the reference's own box tests have been honoured (mesh_walk4).
+// So each mesh gets a four-wide tree built top-down with a binned surface-area heuristic, one triangle
+// per leaf slot, at most RT_STACK / 3 levels deep (the walk pushes up to three siblings per level).
+struct SahTri {
+    uint32_t leaf;  // RT_REF_LEAF | leaf index
+    double lo[3], hi[3], c[3];
+};
+
+static double half_area(const double lo[3], const double hi[3]) {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Partition tris[b, e) into two non-empty parts; returns the split index.  `balanced` forces a median split.
+static size_t sah_split(std::vector<SahTri>& tris, size_t b, size_t e, bool balanced) {
+    const size_t n = e - b;
+    double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = b; i < e; i++)
+        for (int k = 0; k < 3; k++) clo[k] = std::fmin(clo[k], tris[i].c[k]), chi[k] = std::fmax(chi[k], tris[i].c[k]);
+    int wide = 0;
+    for (int k = 1; k < 3; k++)
+        if (chi[k] - clo[k] > chi[wide] - clo[wide]) wide = k;
+    auto median = [&]() {
+        std::nth_element(tris.begin() + b, tris.begin() + b + n / 2, tris.begin() + e,
+                         [wide](const SahTri& x, const SahTri& y) { return x.c[wide] < y.c[wide]; });
+        return b + n / 2;
+    };
+    if (balanced || n <= 2 || !(chi[wide] - clo[wide] > 0)) return median();
+    constexpr int NB = 16;
+    double best = 1e300;
+    int best_axis = -1, best_bin = 0;
+    for (int k = 0; k < 3; k++) {
+        const double ext = chi[k] - clo[k];
+        if (!(ext > 0)) continue;
+        struct Bin {
+            double lo[3], hi[3];
+            size_t n;
+        } bins[NB];
+        for (auto& bn : bins) {
+            bn.n = 0;
+            for (int j = 0; j < 3; j++) bn.lo[j] = 1e300, bn.hi[j] = -1e300;
+        }
+        for (size_t i = b; i < e; i++) {
+            int id = (int)((tris[i].c[k] - clo[k]) / ext * NB);
+            id = id < 0 ? 0 : (id >= NB ? NB - 1 : id);
+            bins[id].n++;
+            for (int j = 0; j < 3; j++) bins[id].lo[j] = std::fmin(bins[id].lo[j], tris[i].lo[j]), bins[id].hi[j] = std::fmax(bins[id].hi[j], tris[i].hi[j]);
+        }
+        double ra[NB];  // cost of everything right of boundary i (bins i..NB-1)
+        {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            size_t cnt = 0;
+            for (int i = NB - 1; i > 0; i--) {
+                for (int j = 0; j < 3; j++) lo[j] = std::fmin(lo[j], bins[i].lo[j]), hi[j] = std::fmax(hi[j], bins[i].hi[j]);
+                cnt += bins[i].n;
+                ra[i] = cnt ? half_area(lo, hi) * (double)cnt : 0.0;
+            }
+        }
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        size_t cnt = 0;
+        for (int i = 1; i < NB; i++) {
+            for (int j = 0; j < 3; j++) lo[j] = std::fmin(lo[j], bins[i - 1].lo[j]), hi[j] = std::fmax(hi[j], bins[i - 1].hi[j]);
+            cnt += bins[i - 1].n;
+            if (cnt == 0 || cnt == n) continue;
+            const double cost = half_area(lo, hi) * (double)cnt + ra[i];
+            if (cost < best) best = cost, best_axis = k, best_bin = i;
+        }
+    }
+    if (best_axis < 0) return median();
+    const double ext = chi[best_axis] - clo[best_axis], c0 = clo[best_axis];
+    const int ax = best_axis, bb = best_bin;
+    auto mid = std::partition(tris.begin() + b, tris.begin() + e, [=](const SahTri& t) {
+        int id = (int)((t.c[ax] - c0) / ext * NB);
+        id = id < 0 ? 0 : (id >= NB ? NB - 1 : id);
+        return id < bb;
+    });
+    const size_t m = (size_t)(mid - tris.begin());
+    return (m == b || m == e) ? median() : m;
+}
+
 static void build_tree4(const rt_scene_desc* d, Tree4& T) {
     T.nodes.clear();
     T.node_parent.assign(d->n_nodes, RT_REF_END);
@@ -717,70 +806,107 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T) {
         if (r != RT_REF_END && !(r & RT_REF_LEAF)) shared = shared || T.node_parent[r] != RT_REF_END;
     }
     if (shared) return;
-    struct Item {
-        uint32_t bnode, idx4;
-        int level;
-    };
+    constexpr int MAX_LEVELS = RT_STACK / 3;
     for (int mi = 0; mi < d->n_meshes; mi++) {
         const uint32_t root = d->meshes[mi].root;
         if (root == RT_REF_END || (root & RT_REF_LEAF)) continue;
-        const size_t first = T.nodes.size();
+        // the triangles of the mesh, and the nesting of the reference's boxes above them (the walk's argument for
+        // keeping a hit without re-running the reference's box tests relies on that nesting)
         bool usable = true;
-        int levels = 0;
-        std::vector<Item> todo{{root, (uint32_t)first, 1}};
-        T.nodes.push_back(DevNode4{});
+        std::vector<SahTri> tris;
+        std::vector<uint32_t> todo{root};
         while (!todo.empty() && usable) {
-            const Item it = todo.back();
+            const uint32_t n = todo.back();
             todo.pop_back();
-            levels = std::max(levels, it.level);
-            uint32_t kids[4];
-            int nk = 0;
             double plo[3], phi[3];
-            ref_bounds(d, it.bnode, plo, phi);
-            for (uint32_t c : {d->nodes[it.bnode].left, d->nodes[it.bnode].right}) {
+            ref_bounds(d, n, plo, phi);
+            for (uint32_t c : {d->nodes[n].left, d->nodes[n].right}) {
                 if (c == RT_REF_END) continue;
                 double clo[3], chi[3];
                 ref_bounds(d, c, clo, chi);
-                for (int k = 0; k < 3; k++) usable = usable && plo[k] <= clo[k] && chi[k] <= phi[k];
+                for (int k = 0; k < 3; k++)
+                    usable = usable && plo[k] <= clo[k] && chi[k] <= phi[k] && std::isfinite(clo[k]) && std::isfinite(chi[k]) &&
+                             std::fabs(clo[k]) < 1e6 && std::fabs(chi[k]) < 1e6;
                 if (c & RT_REF_LEAF) {
-                    kids[nk++] = c;
-                    continue;
+                    SahTri t;
+                    t.leaf = c;
+                    for (int k = 0; k < 3; k++) t.lo[k] = clo[k], t.hi[k] = chi[k], t.c[k] = 0.5 * (clo[k] + chi[k]);
+                    tris.push_back(t);
+                } else {
+                    todo.push_back(c);
                 }
-                for (uint32_t gc : {d->nodes[c].left, d->nodes[c].right}) {
-                    if (gc == RT_REF_END) continue;
-                    double glo[3], ghi[3];
-                    ref_bounds(d, gc, glo, ghi);
-                    for (int k = 0; k < 3; k++) usable = usable && clo[k] <= glo[k] && ghi[k] <= chi[k];
-                    kids[nk++] = gc;
+            }
+        }
+        if (!usable || tris.size() < 2) continue;
+        // capacity check: a level holds four times the triangles of the one above
+        double cap = 1;
+        for (int i = 0; i < MAX_LEVELS; i++) cap *= 4;
+        if ((double)tris.size() > cap) continue;
+
+        struct Item {
+            size_t b, e;
+            uint32_t idx4;
+            int level;  // 1 = root
+        };
+        const size_t first = T.nodes.size();
+        T.nodes.push_back(DevNode4{});
+        std::vector<Item> work{{0, tris.size(), (uint32_t)first, 1}};
+        while (!work.empty()) {
+            const Item it = work.back();
+            work.pop_back();
+            // triangles a child may hold so that its subtree still fits the remaining levels
+            double child_cap = 1;
+            for (int i = it.level; i < MAX_LEVELS; i++) child_cap *= 4;
+            // up to four ranges: split the range, then keep splitting the part with the largest box
+            size_t rb[4], re[4];
+            int nr = 1;
+            rb[0] = it.b, re[0] = it.e;
+            while (nr < 4) {
+                int pick = -1;
+                double pick_key = -1;
+                for (int r = 0; r < nr; r++) {
+                    const size_t n = re[r] - rb[r];
+                    if (n < 2) continue;
+                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                    for (size_t i = rb[r]; i < re[r]; i++)
+                        for (int k = 0; k < 3; k++) lo[k] = std::fmin(lo[k], tris[i].lo[k]), hi[k] = std::fmax(hi[k], tris[i].hi[k]);
+                    // ranges that are too big for the levels left go first, then by area
+                    const double key = ((double)n > child_cap ? 1e300 : 0.0) + half_area(lo, hi) * (double)n;
+                    if (key > pick_key) pick_key = key, pick = r;
                 }
+                if (pick < 0) break;
+                // a node with more triangles than one child may hold is cut into equal parts, which then all fit
+                const bool tight = (double)(it.e - it.b) > child_cap;
+                const size_t m = sah_split(tris, rb[pick], re[pick], tight);
+                for (int r = nr; r > pick + 1; r--) rb[r] = rb[r - 1], re[r] = re[r - 1];
+                re[pick + 1] = re[pick], rb[pick + 1] = m, re[pick] = m;
+                nr++;
             }
             DevNode4 n4;
             std::memset(&n4, 0, sizeof(n4));
             for (int c = 0; c < 4; c++) n4.child[c] = RT_REF_END;
-            for (int c = 0; c < nk; c++) {
-                double lo[3], hi[3];
-                ref_bounds(d, kids[c], lo, hi);
+            for (int c = 0; c < nr; c++) {
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (size_t i = rb[c]; i < re[c]; i++)
+                    for (int k = 0; k < 3; k++) lo[k] = std::fmin(lo[k], tris[i].lo[k]), hi[k] = std::fmax(hi[k], tris[i].hi[k]);
                 for (int k = 0; k < 3; k++) {
-                    usable = usable && std::isfinite(lo[k]) && std::isfinite(hi[k]) && std::fabs(lo[k]) < 1e6 && std::fabs(hi[k]) < 1e6;
                     // a triangle accepted by the double-precision test may lie a rounding error outside its exact bounds
-                    const double pad = (kids[c] & RT_REF_LEAF) ? 1e-9 * (1.0 + std::fabs(lo[k]) + std::fabs(hi[k])) + 1e-7 * (hi[k] - lo[k]) : 0.0;
+                    const double pad = 1e-9 * (1.0 + std::fabs(lo[k]) + std::fabs(hi[k])) + 1e-7 * (hi[k] - lo[k]);
                     n4.lo[k][c] = round_down(lo[k] - pad), n4.hi[k][c] = round_up(hi[k] + pad);
                 }
-                if (kids[c] & RT_REF_LEAF) {
-                    n4.child[c] = kids[c];
+                if (re[c] - rb[c] == 1) {
+                    n4.child[c] = tris[rb[c]].leaf;
                 } else {
                     n4.child[c] = (uint32_t)T.nodes.size();
-                    todo.push_back({kids[c], n4.child[c], it.level + 1});
+                    if ((double)(re[c] - rb[c]) > child_cap || it.level + 1 > MAX_LEVELS) usable = false;
+                    work.push_back({rb[c], re[c], n4.child[c], it.level + 1});
                     T.nodes.push_back(DevNode4{});
                 }
             }
             T.nodes[it.idx4] = n4;
         }
-        if (usable && 3 * levels <= RT_STACK && T.nodes.size() < (1u << 30)) {
-            T.mesh_root4[mi] = (int32_t)first;
-        } else {
-            T.nodes.resize(first);
-        }
+        if (usable && T.nodes.size() < (1u << 30)) T.mesh_root4[mi] = (int32_t)first;
+        else T.nodes.resize(first);
     }
 }
 
