@@ -698,13 +698,32 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
 
 // ---- which primitives can shadow a point from a lamp at all ------------------------------------
 // For a shaded point A and a lamp (centre Lc, every sample within Rl of Lc), every shadow ray of
-// that lamp runs inside the capsule of radius Rl around the segment A..Lc.  A primitive whose
-// bounding ball stays clear of that capsule (or a plane that has A and the whole lamp strictly on
-// one side) reports "no occlusion" for every sample, so its test can be skipped for all of them;
-// bit j of the result is cleared for such primitives.  Radii are inflated so that "clear" holds
-// with rounding to spare.  Under RT_F_MESH_RAW_DIR a mesh / triangle hit counts up to ray parameter
-// |L - A| (CR/Collision_Mesh.cu:19-63 does not normalise the direction), i.e. far beyond the lamp,
-// so their capsule is stretched accordingly.
+// that lamp runs inside the capsule of radius Rl around the segment A..Lc, and inside the cone with
+// apex A that touches the ball (Lc, Rl).  A primitive whose bounding ball stays clear of the capsule
+// or of the cone (or a plane that has A and the whole lamp strictly on one side) reports "no
+// occlusion" for every sample, so its test can be skipped for all of them; bit j of the result is
+// cleared for such primitives.  Radii are inflated so that "clear" holds with rounding to spare.
+// Under RT_F_MESH_RAW_DIR a mesh / triangle hit counts up to ray parameter |L - A|
+// (CR/Collision_Mesh.cu:19-63 does not normalise the direction), i.e. far beyond the lamp, so their
+// capsule is stretched accordingly; the cone needs no stretching, it is unbounded.
+// reciprocal and reciprocal square root good to ~1e-13 (hardware estimate + one Newton step): for the
+// conservative tests below, whose margins are 1e-9 and wider; never on a path that decides a hit
+DEV double approx_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+DEV double approx_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x * y;
+    return __builtin_fma(y, __builtin_fma(-h, y, 0.5), y);
+}
+
+#ifndef RT_CONE_MESH_PASSES
+#define RT_CONE_MESH_PASSES 2
+#endif
+#ifndef RT_CONE_BALL
+#define RT_CONE_BALL 1
+#endif
 DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L) {
     if (sc.n_prims > 64) return ~0ull;
     double Rl = 0.0;
@@ -714,9 +733,18 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
     const d3 Lc = d3{L.O.x, L.O.y, L.O.z}, D = Lc - A;
     const double L2 = dot(D, D);
     if (!(L2 > 1e-200) || !(L2 < 1e200) || !(Rl < 1e100)) return ~0ull;
-    const double inv = 1.0 / L2, len = sqrt(L2);
+    const double inv_len = approx_rsqrt(L2), inv = inv_len * inv_len, len = L2 * inv_len;
     const double s_raw = (len + Rl) * (1.0 + 1e-6), r_raw = Rl * s_raw + 1e-9;  // stretched capsule (raw-direction meshes)
     const bool raw = (flags & RT_F_MESH_RAW_DIR) != 0;
+    // cone: sin and cos^2 of the half-angle, and its radius per unit of the segment parameter s (distance s * len from A)
+    const bool cone = len > 1.001 * Rl;
+    const double sin_a = cone ? Rl * inv_len : 0.0, cos2_a = 1.0 - sin_a * sin_a;
+    const double cone_k = cone ? Rl * approx_rsqrt(cos2_a) * (1.0 + 1e-6) : 0.0;
+    // per-axis reciprocals of the segment direction for the box clips (0 marks an axis the segment does not move along)
+    const double Aa[3] = {A.x, A.y, A.z}, Da[3] = {D.x, D.y, D.z};
+    double iD[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) iD[k] = fabs(Da[k]) > 1e-200 ? approx_rcp(Da[k]) : 0.0;
     unsigned long long m = 0;
     for (int j = 0; j < sc.n_prims; j++) {
         const DevGeom RT_CONST& g = GEOM(sc)[j];
@@ -727,31 +755,46 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
             const double tol = 1e-7 * (1.0 + fabs(sa) + fabs(sl));
             if ((sa > tol && sl > Rl + tol) || (sa < -tol && sl < -(Rl + tol))) may = false;
         } else if (g.type == RT_PRIM_MESH && g.aux0 != RT_REF_END) {
-            // segment A + D*s, 0 <= s <= smax, against the root box grown by the capsule radius
-            const double smax = raw ? s_raw : 1.0, rc = (raw ? r_raw : Rl) + 1e-9 * (1.0 + g.f[MSH_SCALE]);
-            double tlo = 0.0, thi = smax;
-            const double Aa[3] = {A.x, A.y, A.z}, Da[3] = {D.x, D.y, D.z};
+            // segment A + D*s, 0 <= s <= smax, against the root box grown by the radius of the region; the cone
+            // is narrower than the capsule near A, so the radius is lowered to the cone's at the far end of the
+            // overlap found so far and the clip repeated
+            const double smax = raw ? s_raw : 1.0, pad = 1e-9 * (1.0 + g.f[MSH_SCALE]);
+            double rc = (raw ? r_raw : Rl) + pad, thi = smax;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const double lo = g.f[MSH_BMIN + k] - rc, hi = g.f[MSH_BMAX + k] + rc;
-                if (fabs(Da[k]) > 1e-200) {
-                    const double i = 1.0 / Da[k], t1 = (lo - Aa[k]) * i, t2 = (hi - Aa[k]) * i;
-                    tlo = fmax(tlo, fmin(t1, t2));
-                    thi = fmin(thi, fmax(t1, t2));
-                } else if (Aa[k] < lo || Aa[k] > hi) {
-                    thi = -1.0;
+            for (int pass = 0; pass < RT_CONE_MESH_PASSES && may; pass++) {
+                double tlo = 0.0;
+                thi = smax;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double lo = g.f[MSH_BMIN + k] - rc, hi = g.f[MSH_BMAX + k] + rc;
+                    if (iD[k] != 0.0) {
+                        const double t1 = (lo - Aa[k]) * iD[k], t2 = (hi - Aa[k]) * iD[k];
+                        tlo = fmax(tlo, fmin(t1, t2));
+                        thi = fmin(thi, fmax(t1, t2));
+                    } else if (Aa[k] < lo || Aa[k] > hi) {
+                        thi = -1.0;
+                    }
                 }
+                if (tlo > thi * (1.0 + 1e-9) + 1e-12) may = false;
+                if (!cone) break;
+                const double rc2 = thi * (1.0 + 1e-9) * cone_k + 1e-12 * cone_k + pad;
+                if (!(rc2 < rc)) break;
+                rc = rc2;
             }
-            if (tlo > thi * (1.0 + 1e-9) + 1e-12) may = false;
         } else {
             const bool stretched = raw && (g.type == RT_PRIM_MESH || g.type == RT_PRIM_TRIANGLE);
             const double smax = stretched ? s_raw : 1.0, rc = stretched ? r_raw : Rl;
             const d3 w = G3(g, BND_C) - A;
-            double sp = dot(w, D) * inv;
-            sp = fmin(fmax(sp, 0.0), smax);
+            const double spu = dot(w, D) * inv, sp = fmin(fmax(spu, 0.0), smax);
             const d3 e = w - D * sp;
-            const double rr = g.f[BND_R] + rc;
-            if (dot(e, e) > rr * rr * (1.0 + 1e-9)) may = false;
+            const double rb = g.f[BND_R], rr = rb + rc, ee = dot(e, e);
+            if (ee > rr * rr * (1.0 + 1e-9)) may = false;
+            if (RT_CONE_BALL && cone && spu > 0.0 && spu <= smax) {
+                // beside the segment: e is the offset of the ball's centre from the axis, and its distance from the
+                // cone's surface is |e| cos(a) - (distance along the axis) sin(a) = |e| cos(a) - spu * Rl
+                const double q = rb * (1.0 + 1e-6) + 1e-9 * (1.0 + len) + spu * Rl;
+                if (ee * cos2_a > q * q * (1.0 + 1e-9)) may = false;
+            }
         }
         if (may) m |= 1ull << j;
     }
