@@ -415,7 +415,7 @@ DEV void trace_batch(const RenderParams& P, const Tile tile, int blk_in_tile, in
 
 // ---- the render kernel: CR/RayTracer.cu:40-94 --------------------------------------------------
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 4  // register budget: 512 / RT_WAVES_PER_SIMD VGPR+AGPR per lane
+#define RT_WAVES_PER_SIMD 3  // register budget: 512 / RT_WAVES_PER_SIMD VGPRs per lane; measured best (2: 100 ms, 3: 96 ms, 4: 113 ms per frame)
 #endif
 template <bool STRICT>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
