@@ -30,6 +30,7 @@
 
 static_assert(sizeof(rt_bvh_node) == 64 && sizeof(rt_bvh_leaf) == 96, "BVH record sizes are part of the ABI");
 static_assert(RT_SPEC_POWER == 20, "the specular power is expanded by hand in diffusion_coop");
+static_assert(sizeof(DevShade) == 216 && sizeof(DevShade) % 4 == 0, "shading record");
 static_assert(sizeof(DevNode4) == 128 && sizeof(DevGeom) == 192, "device record sizes");
 static_assert(sizeof(rt_primitive) == 408 && sizeof(rt_light) == 112 && sizeof(rt_scene_desc) == 256 && sizeof(rt_settings) == 40 &&
                   sizeof(rt_stats) == 80,
@@ -97,17 +98,17 @@ DEV uint32_t to_u8(double c) {
 // ---- CalnDiffusion for every lane that needs it, shadow rays dealt over the wave ---------------
 // CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
 template <bool STRICT>
-DEV d3 diffusion_coop(const RenderParams& P, unsigned long long mask, bool need, const Hit& h, uint32_t& draw, uint32_t pixel,
-                      uint32_t smp, Counters& ctr, uint32_t* stk) {
+DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
+                      uint32_t pixel, uint32_t smp, Counters& ctr, uint32_t* stk) {
     const DevScene& sc = P.sc;
     const int lane = lane_id();
     d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
     double m_diff = 0.0, m_spec = 0.0;
     if (need) {
-        const rt_material& m = sc.prims[h.prim].material;
+        const DevShade& m = shade[h.prim];
         color = D3(m.color);
         m_diff = m.diff, m_spec = m.spec;
-        if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, h, ctr));
+        if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, m, h, ctr));
         ctr.shaded++;
     }
     RT_LAP(ctr, PF_SHADE_SETUP);
@@ -226,8 +227,8 @@ enum { ST_REFL = 1, ST_REFR = 2, ST_PENDING_REFR = 4, ST_FRONT = 8 };
 // lane; a lane whose path has ended takes the next unstarted one, so the lanes stay busy until the
 // round runs out ("path regeneration").  Finished colours go to buf[p].
 template <bool STRICT>
-DEV void trace_batch(const RenderParams& P, const Tile tile, int blk_in_tile, int slot0, int n_slots, int s_begin, int s_end,
-                     double* buf, Counters& ctr, uint32_t* stk) {
+DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile tile, int blk_in_tile, int slot0, int n_slots, int s_begin,
+                     int s_end, double* buf, Counters& ctr, uint32_t* stk) {
     const DevScene& sc = P.sc;
     const int ns = s_end - s_begin;
     const int n_paths = n_slots * ns;
@@ -304,8 +305,8 @@ DEV void trace_batch(const RenderParams& P, const Tile tile, int blk_in_tile, in
                 d3 c = unit(d);
                 double t = 0.5 * (((P.flags & RT_F_SKY_Y) ? c.y : c.z) + 1.0);
                 result = clamp1(sc.bg_bottom * (1.0 - t) + sc.bg_top * t);
-            } else if (sc.prims[h.prim].is_light) {
-                result = clamp1(D3(sc.prims[h.prim].material.color));
+            } else if (shade[h.prim].is_light) {
+                result = clamp1(D3(shade[h.prim].color));
             } else {
                 surface = true;
             }
@@ -313,17 +314,17 @@ DEV void trace_batch(const RenderParams& P, const Tile tile, int blk_in_tile, in
         RT_LAP(ctr, PF_CLOSEST_PRIMS);
         bool need_shade = false;
         if (surface) {
-            const rt_material& m = sc.prims[h.prim].material;
+            const DevShade& m = shade[h.prim];
             need_shade = m.diff > RT_EPS || m.spec > RT_EPS;
         }
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);
-        if (mask != 0ull) local = diffusion_coop<STRICT>(P, mask, need_shade, h, draw, pixel, smp, ctr, stk);
+        if (mask != 0ull) local = diffusion_coop<STRICT>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk);
 
         if (tracing) {
             bool have_result = !surface;
             if (surface) {
-                const rt_material& m = sc.prims[h.prim].material;
+                const DevShade& m = shade[h.prim];
                 d3 acc = D3(0, 0, 0);
                 if (need_shade) acc = acc + local;
                 const bool has_refl = m.refl > RT_EPS, has_refr = m.refr > RT_EPS;
@@ -381,7 +382,7 @@ DEV void trace_batch(const RenderParams& P, const Tile tile, int blk_in_tile, in
                     break;
                 }
                 const int k = sp - 1;
-                const rt_material& m = sc.prims[f_prim[k]].material;
+                const DevShade& m = shade[f_prim[k]];
                 const uint32_t st = f_stage[k];
                 d3 contrib;
                 if (st & ST_REFL) {
@@ -423,6 +424,17 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
     __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
     uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
+    // the shading table moves to LDS when it fits: every hit reads a few of its fields, one after another
+    __shared__ DevShade s_shade[RT_SHADE_LDS];
+    const DevShade* shade = P.sc.shade;
+    if (P.sc.n_prims <= RT_SHADE_LDS) {
+        const int words = P.sc.n_prims * (int)(sizeof(DevShade) / 4);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.sc.shade);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_shade);
+        for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+        __syncthreads();
+        shade = s_shade;
+    }
     Counters ctr;
     ctr.rays_secondary = ctr.rays_shadow = ctr.nodes = ctr.tris = ctr.shaded = ctr.texfetch = 0;
 #ifdef RT_UTIL_COUNTERS
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
         d3 acc = D3(0, 0, 0);
         for (int s0 = 0; s0 < spp; s0 += round) {
             const int s1 = s0 + round < spp ? s0 + round : spp;
-            trace_batch<STRICT>(P, tile, blk_in_tile, slot0, S, s0, s1, buf, ctr, stk);
+            trace_batch<STRICT>(P, shade, tile, blk_in_tile, slot0, S, s0, s1, buf, ctr, stk);
             // Pixel sums: lane j adds the samples of slot j in sample order (the reference adds them in that order
             // inside one thread, CR/RayTracer.cu:74-84).  The colours were written by other lanes of this wave; a
             // fence of work-group scope orders them before the reads without flushing the CU's vector cache, which
@@ -910,6 +922,39 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T) {
     }
 }
 
+static void build_shade(const rt_primitive& p, const DevPrimX& x, DevShade& o) {
+    using namespace hostmath;
+    std::memset(&o, 0, sizeof(o));
+    const rt_material& m = p.material;
+    o.color[0] = m.color.x, o.color[1] = m.color.y, o.color[2] = m.color.z;
+    o.absor[0] = m.absor.x, o.absor[1] = m.absor.y, o.absor[2] = m.absor.z;
+    o.diff = m.diff, o.spec = m.spec, o.refl = m.refl, o.refr = m.refr, o.rindex = m.rindex, o.drefl = m.drefl;
+    o.type = p.type, o.texture = m.texture, o.is_light = p.is_light;
+    o.tex_w = x.tex_w, o.tex_h = x.tex_h, o.tex_off = x.tex_off;
+    auto put3 = [&](int i, h3 v) { o.tf[i] = v.x, o.tf[i + 1] = v.y, o.tf[i + 2] = v.z; };
+    switch (p.type) {
+        case RT_PRIM_SPHERE:
+            put3(TF_SPH_O, H(p.u.sphere.O)), put3(TF_SPH_DE, H(p.u.sphere.De)), put3(TF_SPH_DC, H(p.u.sphere.Dc));
+            put3(TF_SPH_X, hcross(H(p.u.sphere.Dc), H(p.u.sphere.De)));
+            break;
+        case RT_PRIM_PLANE:
+            put3(TF_PLN_DX, H(p.u.plane.Dx)), put3(TF_PLN_DY, H(p.u.plane.Dy));
+            o.tf[TF_PLN_DXX] = hdot(H(p.u.plane.Dx), H(p.u.plane.Dx)), o.tf[TF_PLN_DYY] = hdot(H(p.u.plane.Dy), H(p.u.plane.Dy));
+            break;
+        case RT_PRIM_SQUARE:
+            put3(TF_SQR_O, H(p.u.square.O)), put3(TF_SQR_DX, H(p.u.square.Dx)), put3(TF_SQR_DY, H(p.u.square.Dy));
+            o.tf[TF_SQR_DXX] = hdot(H(p.u.square.Dx), H(p.u.square.Dx)), o.tf[TF_SQR_DYY] = hdot(H(p.u.square.Dy), H(p.u.square.Dy));
+            break;
+        case RT_PRIM_CYLINDER: {
+            const h3 O1 = H(p.u.cylinder.O1), O2 = H(p.u.cylinder.O2);
+            put3(TF_CYL_O1, O1), put3(TF_CYL_O2, O2), put3(TF_CYL_AX, hunit(O2 - O1));
+            o.tf[TF_CYL_LEN] = hmodule(O2 - O1), o.tf[TF_CYL_R] = p.u.cylinder.R;
+            break;
+        }
+        default: break;
+    }
+}
+
 static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g, std::vector<DevGeom>& segs, const Tree4& T) {
     using namespace hostmath;
     std::memset(&g, 0, sizeof(g));
@@ -1056,6 +1101,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 
     // one slab: lights | geometry | Bezier segments | primitives | primitive extras | nodes | four-wide nodes | parents | leaves | texels, one copy
     std::vector<DevPrimX> px((size_t)d->n_primitives);
+    std::vector<DevShade> shade((size_t)d->n_primitives);
     std::vector<DevGeom> geom((size_t)d->n_primitives), segs;
     std::vector<uint32_t> tex_off((size_t)d->n_textures);
     Tree4 T;
@@ -1075,13 +1121,15 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             x.tex_w = t.width, x.tex_h = t.height, x.tex_off = tex_off[p.material.texture];
         }
         build_geom(d, p, geom[i], segs, T);
+        build_shade(p, x, shade[i]);
     }
     size_t off_l = 0;
     size_t off_g = align_up(off_l + sizeof(rt_light) * d->n_lights, 256);
     size_t off_s = align_up(off_g + sizeof(DevGeom) * d->n_primitives, 256);
     size_t off_p = align_up(off_s + sizeof(DevGeom) * segs.size(), 256);
     size_t off_x = align_up(off_p + sizeof(rt_primitive) * d->n_primitives, 256);
-    size_t off_n = align_up(off_x + sizeof(DevPrimX) * d->n_primitives, 256);
+    size_t off_sh = align_up(off_x + sizeof(DevPrimX) * d->n_primitives, 256);
+    size_t off_n = align_up(off_sh + sizeof(DevShade) * d->n_primitives, 256);
     size_t off_n2 = align_up(off_n + sizeof(rt_bvh_node) * (size_t)d->n_nodes, 256);
     size_t off_np = align_up(off_n2 + sizeof(DevNode4) * T.nodes.size(), 256);
     size_t off_lp = align_up(off_np + sizeof(uint32_t) * (size_t)d->n_nodes, 256);
@@ -1094,6 +1142,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!segs.empty()) std::memcpy(&host[off_s], segs.data(), sizeof(DevGeom) * segs.size());
     if (d->n_primitives) std::memcpy(&host[off_p], d->primitives, sizeof(rt_primitive) * d->n_primitives);
     if (d->n_primitives) std::memcpy(&host[off_x], px.data(), sizeof(DevPrimX) * d->n_primitives);
+    if (d->n_primitives) std::memcpy(&host[off_sh], shade.data(), sizeof(DevShade) * d->n_primitives);
     if (d->n_nodes) std::memcpy(&host[off_n], d->nodes, sizeof(rt_bvh_node) * (size_t)d->n_nodes);
     if (!T.nodes.empty()) std::memcpy(&host[off_n2], T.nodes.data(), sizeof(DevNode4) * T.nodes.size());
     if (d->n_nodes) std::memcpy(&host[off_np], T.node_parent.data(), sizeof(uint32_t) * (size_t)d->n_nodes);
@@ -1123,6 +1172,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.segs = (const DevGeom*)(base + off_s);
     v.prims = (const rt_primitive*)(base + off_p);
     v.primx = (const DevPrimX*)(base + off_x);
+    v.shade = (const DevShade*)(base + off_sh);
     v.nodes = (const rt_bvh_node*)(base + off_n);
     v.nodes4 = (const DevNode4*)(base + off_n2);
     v.node_parent = (const uint32_t*)(base + off_np);

@@ -20,6 +20,7 @@ struct d3 {
 
 DEV d3 D3(double x, double y, double z) { return d3{x, y, z}; }
 DEV d3 D3(const rt_vec3& v) { return d3{v.x, v.y, v.z}; }
+DEV d3 D3(const double (&v)[3]) { return d3{v[0], v[1], v[2]}; }
 DEV d3 operator+(d3 a, d3 b) { return d3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 DEV d3 operator-(d3 a, d3 b) { return d3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 DEV d3 operator-(d3 a) { return d3{-a.x, -a.y, -a.z}; }

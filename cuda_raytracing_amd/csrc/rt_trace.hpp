@@ -49,7 +49,23 @@ struct DevNode4 {    // 128 bytes
     uint32_t pad_[4];
 };
 
-// Per-primitive shading extras (indexed per lane at a hit).
+// Everything shading needs to know about a primitive, indexed per lane at a hit: material, texture
+// and the frame the texture coordinates are taken in, with the ray-independent parts of
+// CR/Primitive.cu:16-83 computed once on the host (same IEEE operations).  The kernel keeps the table
+// in LDS when the scene has at most RT_SHADE_LDS primitives.
+#define RT_SHADE_LDS 64
+struct DevShade {  // 216 bytes
+    double color[3], absor[3], diff, spec, refl, refr, rindex, drefl;
+    double tf[12];  // sphere: O, De, Dc, Dc x De | plane: Dx, Dy, Dx.Dx, Dy.Dy | square: O, Dx, Dy, Dx.Dx, Dy.Dy
+                    // cylinder: O1, O2, unit(O2 - O1), |O2 - O1|, R
+    int32_t type, texture, is_light, tex_w, tex_h;
+    uint32_t tex_off;  // byte offset of the texture in the texel pool
+};
+enum { TF_SPH_O = 0, TF_SPH_DE = 3, TF_SPH_DC = 6, TF_SPH_X = 9, TF_PLN_DX = 0, TF_PLN_DY = 3, TF_PLN_DXX = 6, TF_PLN_DYY = 7,
+       TF_SQR_O = 0, TF_SQR_DX = 3, TF_SQR_DY = 6, TF_SQR_DXX = 9, TF_SQR_DYY = 10, TF_CYL_O1 = 0, TF_CYL_O2 = 3, TF_CYL_AX = 6,
+       TF_CYL_LEN = 9, TF_CYL_R = 10 };
+
+// Per-primitive shading extras (superseded by DevShade; kept for the record layout of the slab).
 struct DevPrimX {
     int32_t tex_w, tex_h;
     uint32_t tex_off;  // byte offset of the texture in the texel pool
@@ -65,6 +81,7 @@ struct DevScene {
     const DevGeom* segs;           // read as RT_CONST, Bezier cylinder segments
     const rt_primitive* prims;     // materials + texture frames, per-lane lookups
     const DevPrimX* primx;
+    const DevShade* shade;         // global copy of the shading table
     const rt_bvh_node* nodes;
     const DevNode4* nodes4;        // collapsed tree of the pruned walk
     const uint32_t* node_parent;   // per rt_bvh_node: parent node (RT_REF_END at a root)
@@ -867,7 +884,7 @@ DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int c
 }
 
 // ---- textures: CR/bmp.cpp:133-150 (double taps), CR/Primitive.cu:85-115 (8-bit taps) --------
-DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevPrimX& px, double u, double v) {
+DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevShade& px, double u, double v) {
     const int H = px.tex_h, W = px.tex_w;
     const bool u8 = (flags & RT_F_TEX_U8_TAPS) != 0;
     double U = (u - (u8 ? (double)floorf((float)u) : floor(u))) * H;
@@ -912,45 +929,42 @@ DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevPrimX& px, doub
 }
 
 // CR/Primitive.cu:16-83, CR/primitive.cpp:140-147,177-181,229-233
-DEV d3 texture_color(const DevScene& sc, uint32_t flags, const Hit& c, Counters& ctr) {
-    const rt_primitive& p = sc.prims[c.prim];
-    const DevPrimX& px = sc.primx[c.prim];
+DEV d3 T3(const DevShade& p, int i) { return d3{p.tf[i], p.tf[i + 1], p.tf[i + 2]}; }
+DEV d3 texture_color(const DevScene& sc, uint32_t flags, const DevShade& p, const Hit& c, Counters& ctr) {
     double u, v;
     switch (p.type) {
         case RT_PRIM_SPHERE: {
-            d3 I = unit(c.C - D3(p.u.sphere.O));
-            double a = acos(-dot(I, D3(p.u.sphere.De)));
-            double b = acos(fmin(fmax(dot(I, D3(p.u.sphere.Dc)) / sin(a), -1.0), 1.0));
+            d3 I = unit(c.C - T3(p, TF_SPH_O));
+            double a = acos(-dot(I, T3(p, TF_SPH_DE)));
+            double b = acos(fmin(fmax(dot(I, T3(p, TF_SPH_DC)) / sin(a), -1.0), 1.0));
             u = a / M_PI, v = b / 2 / M_PI;
-            if (dot(I, cross(D3(p.u.sphere.Dc), D3(p.u.sphere.De))) < 0) v = 1 - v;
+            if (dot(I, T3(p, TF_SPH_X)) < 0) v = 1 - v;
             break;
         }
         case RT_PRIM_PLANE: {
-            d3 Dx = D3(p.u.plane.Dx), Dy = D3(p.u.plane.Dy);
-            u = dot(c.C, Dx) / dot(Dx, Dx);
-            v = dot(c.C, Dy) / dot(Dy, Dy);
+            u = dot(c.C, T3(p, TF_PLN_DX)) / p.tf[TF_PLN_DXX];
+            v = dot(c.C, T3(p, TF_PLN_DY)) / p.tf[TF_PLN_DYY];
             break;
         }
         case RT_PRIM_SQUARE: {
-            d3 Dx = D3(p.u.square.Dx), Dy = D3(p.u.square.Dy);
-            d3 b = (flags & RT_F_SQUARE_UV_NO_ORIGIN) ? c.C : c.C - D3(p.u.square.O);
-            u = dot(b, Dx) / dot(Dx, Dx) / 2 + 0.5;
-            v = dot(b, Dy) / dot(Dy, Dy) / 2 + 0.5;
+            d3 b = (flags & RT_F_SQUARE_UV_NO_ORIGIN) ? c.C : c.C - T3(p, TF_SQR_O);
+            u = dot(b, T3(p, TF_SQR_DX)) / p.tf[TF_SQR_DXX] / 2 + 0.5;
+            v = dot(b, T3(p, TF_SQR_DY)) / p.tf[TF_SQR_DYY] / 2 + 0.5;
             break;
         }
         case RT_PRIM_CYLINDER: {
-            d3 O1 = D3(p.u.cylinder.O1), O2 = D3(p.u.cylinder.O2);
+            d3 O1 = T3(p, TF_CYL_O1), O2 = T3(p, TF_CYL_O2);
             if (!c.front) {
                 d3 cp = c.C - O1;
                 double ang = atan2(cp.z, cp.x);
                 if (ang < 0) ang += 2 * M_PI;
                 u = ang / (2 * M_PI);
-                v = dot(c.C - O1, unit(O2 - O1)) / module(O2 - O1);
+                v = dot(c.C - O1, T3(p, TF_CYL_AX)) / p.tf[TF_CYL_LEN];
             } else {
                 d3 cc = module(c.C - O1) < module(c.C - O2) ? O1 : O2;
                 d3 l = c.C - cc;
-                u = l.x / (2.0 * p.u.cylinder.R) + 0.5;
-                v = l.z / (2.0 * p.u.cylinder.R) + 0.5;
+                u = l.x / (2.0 * p.tf[TF_CYL_R]) + 0.5;
+                v = l.z / (2.0 * p.tf[TF_CYL_R]) + 0.5;
             }
             break;
         }
@@ -958,7 +972,7 @@ DEV d3 texture_color(const DevScene& sc, uint32_t flags, const Hit& c, Counters&
             return D3(0, 0, 0);
     }
     ctr.texfetch++;
-    return smooth_color(sc, flags, px, u, v);
+    return smooth_color(sc, flags, p, u, v);
 }
 
 // Point on a light for sample draws (a, b): CR/Shade.cu:3-21
