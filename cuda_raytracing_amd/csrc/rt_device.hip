@@ -61,8 +61,11 @@ struct RenderParams {
     double* path_buf;  // RT_BATCH_PATHS * 3 doubles per wave of the grid: colours of finished paths
     unsigned long long* counters;
 };
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 24  // idle lanes that trigger a refill (measured: 1: 94 ms, 16: 91, 24-32: 91 at 256 paths per round)
+#endif
 #ifndef RT_BATCH_PATHS
-#define RT_BATCH_PATHS 256  // paths of one task round: in flight (one per lane) or waiting for a lane
+#define RT_BATCH_PATHS 1024  // paths of one task round: in flight (one per lane) or waiting for a lane (256: 91 ms, 512: 87, 1024: 84, 2048: 90)
 #endif
 
 enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT,
@@ -245,8 +248,9 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
 
     for (;;) {
         // ---- idle lanes start the next paths of the round (CR/RayTracer.cu:52-72) ----
-        if (next < n_paths) {
-            const unsigned long long idle = __ballot(!tracing);
+        // (only when enough lanes wait: the set-up below is long, and running it for one lane costs the same)
+        const unsigned long long idle = __ballot(!tracing);
+        if (next < n_paths && (__popcll(idle) >= RT_REFILL_MIN || idle == ~0ull)) {
             const int p = next + rank_in(idle);
             if (!tracing && p < n_paths) {
                 const int q = p / ns, s = s_begin + (p - q * ns), inb = slot0 + q;
