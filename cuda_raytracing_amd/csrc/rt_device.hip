@@ -136,7 +136,7 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             if (!(dt > RT_EPS)) {
                 work = false;
             } else {
-                cand = light_candidates(sc, P.flags, h.C, L);
+                cand = light_candidates(sc, P.flags, h.C, L, l);
                 if (P.flags & RT_F_SHADOW_SELF_SKIP) cand &= ~(h.prim < 64 ? 1ull << h.prim : 0ull);
                 if (L.light_primitive >= 0 && L.light_primitive < 64) cand &= ~(1ull << L.light_primitive);
                 if (cand == 0ull) work = false, cnt = n_l;
@@ -1072,6 +1072,115 @@ static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g
     }
 }
 
+// ---- candidate grid: which primitives can stand between a cell's points and a lamp -------------------
+// Same reasoning as light_candidates on the device, for every point of a cell at once: the cell is a ball
+// (centre, rho) and every segment from one of its points to the lamp's ball stays within rho of the capsule
+// around centre..lamp.  Meshes and triangles always get the capsule stretched as under RT_F_MESH_RAW_DIR (the
+// mode is not known here; the stretched capsule contains the plain one).
+static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& geom, std::vector<unsigned long long>& grid, double lo[3],
+                            double inv[3]) {
+    using namespace hostmath;
+    grid.clear();
+    if (d->n_primitives > 64 || d->n_lights <= 0 || d->n_primitives <= 0) return;
+    // bounds of everything bounded, the lamps and the camera
+    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+    auto grow = [&](h3 c, double r) {
+        const double v[3] = {c.x, c.y, c.z};
+        for (int k = 0; k < 3; k++) blo[k] = std::fmin(blo[k], v[k] - r), bhi[k] = std::fmax(bhi[k], v[k] + r);
+    };
+    for (int j = 0; j < d->n_primitives; j++) {
+        const DevGeom& g = geom[j];
+        if (g.type == RT_PRIM_PLANE) continue;
+        if (g.type == RT_PRIM_MESH) {
+            if (g.aux0 == RT_REF_END) continue;
+            grow(h3{g.f[MSH_BMIN], g.f[MSH_BMIN + 1], g.f[MSH_BMIN + 2]}, 0), grow(h3{g.f[MSH_BMAX], g.f[MSH_BMAX + 1], g.f[MSH_BMAX + 2]}, 0);
+        } else if (g.f[BND_R] < 1e100) {
+            grow(h3{g.f[BND_C], g.f[BND_C + 1], g.f[BND_C + 2]}, g.f[BND_R]);
+        }
+    }
+    std::vector<double> lamp_r(d->n_lights);
+    for (int l = 0; l < d->n_lights; l++) {
+        const rt_light& L = d->lights[l];
+        double Rl = 0;
+        if (L.type == RT_LIGHT_SPHERE) Rl = std::fabs(L.R);
+        else if (L.type == RT_LIGHT_SQUARE) Rl = hmodule(H(L.Dx)) + hmodule(H(L.Dy));
+        lamp_r[l] = Rl * (1.0 + 1e-6) + 1e-9;
+        grow(H(L.O), lamp_r[l]);
+    }
+    grow(H(d->camera.O), 0);
+    for (int k = 0; k < 3; k++) {
+        if (!(bhi[k] >= blo[k]) || !std::isfinite(blo[k]) || !std::isfinite(bhi[k])) return;
+        const double ext = std::fmax(bhi[k] - blo[k], 1e-3), pad = 0.25 * ext;
+        blo[k] -= pad, bhi[k] += pad;
+        lo[k] = blo[k];
+        inv[k] = RT_CGRID / (bhi[k] - blo[k]);
+    }
+    const double cell[3] = {1.0 / inv[0], 1.0 / inv[1], 1.0 / inv[2]};
+    // a cell's points are those whose computed index is this cell: allow for the rounding of the index arithmetic
+    const double rho = 0.5 * std::sqrt(cell[0] * cell[0] + cell[1] * cell[1] + cell[2] * cell[2]) * (1.0 + 1e-6) + 1e-9;
+    const size_t per_lamp = (size_t)RT_CGRID * RT_CGRID * RT_CGRID;
+    grid.assign(per_lamp * d->n_lights, 0ull);
+    for (int l = 0; l < d->n_lights; l++) {
+        const h3 Lc = H(d->lights[l].O);
+        const double Rl = lamp_r[l];
+        for (int iz = 0; iz < RT_CGRID; iz++)
+            for (int iy = 0; iy < RT_CGRID; iy++)
+                for (int ix = 0; ix < RT_CGRID; ix++) {
+                    const h3 A{lo[0] + (ix + 0.5) * cell[0], lo[1] + (iy + 0.5) * cell[1], lo[2] + (iz + 0.5) * cell[2]};
+                    const h3 D = Lc - A;
+                    const double L2 = hdot(D, D), len = std::sqrt(L2);
+                    unsigned long long m = 0;
+                    for (int j = 0; j < d->n_primitives; j++) {
+                        const DevGeom& g = geom[j];
+                        bool may = true;
+                        if (!(L2 > 1e-200)) {
+                        } else if (g.type == RT_PRIM_PLANE) {
+                            const h3 N{g.f[PLN_N], g.f[PLN_N + 1], g.f[PLN_N + 2]}, Q{g.f[PLN_NR], g.f[PLN_NR + 1], g.f[PLN_NR + 2]};
+                            const double sa = hdot(A - Q, N), sl = hdot(Lc - Q, N);
+                            const double tol = 1e-7 * (1.0 + std::fabs(sa) + std::fabs(sl)) + rho;
+                            if ((sa > tol && sl > Rl + tol) || (sa < -tol && sl < -(Rl + tol))) may = false;
+                        } else if (g.type == RT_PRIM_MESH && g.aux0 != RT_REF_END) {
+                            // a point A' + s (T - A') of a shadow segment (|A' - A| <= rho, |T - Lc| <= Rl) lies within
+                            // |1 - s| rho + s Rl of A + s D: clip with the largest such radius, then again with the
+                            // largest radius inside the overlap found
+                            const double smax = (len + rho + Rl) * (1.0 + 1e-6), pad = 1e-9 * (1.0 + g.f[MSH_SCALE]);
+                            double rc = smax * (Rl + rho) + pad;
+                            const double Aa[3] = {A.x, A.y, A.z}, Da[3] = {D.x, D.y, D.z};
+                            for (int pass = 0; pass < 3 && may; pass++) {
+                                double tlo = 0.0, thi = smax;
+                                for (int k = 0; k < 3; k++) {
+                                    const double blo_k = g.f[MSH_BMIN + k] - rc, bhi_k = g.f[MSH_BMAX + k] + rc;
+                                    if (std::fabs(Da[k]) > 1e-200) {
+                                        const double i = 1.0 / Da[k], t1 = (blo_k - Aa[k]) * i, t2 = (bhi_k - Aa[k]) * i;
+                                        tlo = std::fmax(tlo, std::fmin(t1, t2)), thi = std::fmin(thi, std::fmax(t1, t2));
+                                    } else if (Aa[k] < blo_k || Aa[k] > bhi_k) {
+                                        thi = -1.0;
+                                    }
+                                }
+                                if (tlo > thi * (1.0 + 1e-9) + 1e-12) may = false;
+                                if (!may) break;
+                                const double th = thi * (1.0 + 1e-9) + 1e-12;
+                                const double rc2 = std::fmax(rho, std::fabs(1.0 - th) * rho + th * Rl) * (1.0 + 1e-9) + pad;
+                                if (!(rc2 < rc)) break;
+                                rc = rc2;
+                            }
+                        } else if (g.f[BND_R] < 1e100) {
+                            const bool stretched = g.type == RT_PRIM_MESH || g.type == RT_PRIM_TRIANGLE;
+                            const double smax = stretched ? (len + rho + Rl) * (1.0 + 1e-6) : 1.0, rc = stretched ? smax * (Rl + rho) : Rl + rho;
+                            const h3 w = h3{g.f[BND_C], g.f[BND_C + 1], g.f[BND_C + 2]} - A;
+                            double sp = hdot(w, D) / L2;
+                            sp = std::fmin(std::fmax(sp, 0.0), smax);
+                            const h3 e = w - D * sp;
+                            const double rr = g.f[BND_R] + rc;
+                            if (hdot(e, e) > rr * rr * (1.0 + 1e-9)) may = false;
+                        }
+                        if (may) m |= 1ull << j;
+                    }
+                    grid[((size_t)l * RT_CGRID + iz) * RT_CGRID * RT_CGRID + (size_t)iy * RT_CGRID + ix] = m;
+                }
+    }
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" void rt_scene_destroy(rt_scene* s) {
@@ -1138,7 +1247,11 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     size_t off_np = align_up(off_n2 + sizeof(DevNode4) * T.nodes.size(), 256);
     size_t off_lp = align_up(off_np + sizeof(uint32_t) * (size_t)d->n_nodes, 256);
     size_t off_f = align_up(off_lp + sizeof(uint32_t) * (size_t)d->n_leaves, 256);
-    size_t off_t = align_up(off_f + sizeof(rt_bvh_leaf) * (size_t)d->n_leaves, 256);
+    std::vector<unsigned long long> cgrid;
+    double cg_lo[3] = {0, 0, 0}, cg_inv[3] = {0, 0, 0};
+    build_cand_grid(d, geom, cgrid, cg_lo, cg_inv);
+    size_t off_cg = align_up(off_f + sizeof(rt_bvh_leaf) * (size_t)d->n_leaves, 256);
+    size_t off_t = align_up(off_cg + sizeof(unsigned long long) * cgrid.size(), 256);
     s->slab_bytes = align_up(off_t + texel_bytes, 256) + 256;
     std::vector<uint8_t> host(s->slab_bytes, 0);
     if (d->n_lights) std::memcpy(&host[off_l], d->lights, sizeof(rt_light) * d->n_lights);
@@ -1152,6 +1265,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (d->n_nodes) std::memcpy(&host[off_np], T.node_parent.data(), sizeof(uint32_t) * (size_t)d->n_nodes);
     if (d->n_leaves) std::memcpy(&host[off_lp], T.leaf_parent.data(), sizeof(uint32_t) * (size_t)d->n_leaves);
     if (d->n_leaves) std::memcpy(&host[off_f], d->leaves, sizeof(rt_bvh_leaf) * (size_t)d->n_leaves);
+    if (!cgrid.empty()) std::memcpy(&host[off_cg], cgrid.data(), sizeof(unsigned long long) * cgrid.size());
     for (int i = 0; i < d->n_textures; i++)
         std::memcpy(&host[off_t + tex_off[i]], d->textures[i].rgb, (size_t)d->textures[i].width * d->textures[i].height * 3);
     HIPCHK(hipMalloc(&s->slab, s->slab_bytes));
@@ -1183,6 +1297,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.leaf_parent = (const uint32_t*)(base + off_lp);
     v.leaves = (const rt_bvh_leaf*)(base + off_f);
     v.texels = base + off_t;
+    v.cand_grid = cgrid.empty() ? nullptr : (const unsigned long long*)(base + off_cg);
+    for (int k = 0; k < 3; k++) v.cg_lo[k] = cg_lo[k], v.cg_inv[k] = cg_inv[k];
 
     HIPCHK(hipMalloc(&s->queue, 256));
     HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * (CTR_ALL + 16)));

@@ -53,6 +53,7 @@ struct DevNode4 {    // 128 bytes
 // and the frame the texture coordinates are taken in, with the ray-independent parts of
 // CR/Primitive.cu:16-83 computed once on the host (same IEEE operations).  The kernel keeps the table
 // in LDS when the scene has at most RT_SHADE_LDS primitives.
+#define RT_CGRID 64
 #define RT_SHADE_LDS 64
 struct DevShade {  // 216 bytes
     double color[3], absor[3], diff, spec, refl, refr, rindex, drefl;
@@ -76,6 +77,10 @@ struct DevScene {
     d3 bg_top, bg_bottom, camO, camN, camDx, camDy;
     int32_t cam_w, cam_h, shade_n, n_lights, n_prims;
     unsigned long long mesh_mask;  // bit j set: primitive j (< 64) is a mesh
+    // Coarse answer to "which primitives can stand between a point and lamp l": a grid of RT_CGRID^3 cells over the
+    // scene's bounded part, one 64-bit primitive mask per cell and lamp (null if the scene has more than 64 primitives).
+    const unsigned long long* cand_grid;  // [lamp][z][y][x]
+    double cg_lo[3], cg_inv[3];           // cell index = floor((p - cg_lo) * cg_inv)
     const rt_light* lights;        // read as RT_CONST
     const DevGeom* geom;           // read as RT_CONST, one per primitive
     const DevGeom* segs;           // read as RT_CONST, Bezier cylinder segments
@@ -741,8 +746,18 @@ DEV double approx_rsqrt(double x) {
 #ifndef RT_CONE_BALL
 #define RT_CONE_BALL 1
 #endif
-DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L) {
+DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp) {
     if (sc.n_prims > 64) return ~0ull;
+    // the cell's mask first: most points have nothing near their way to the lamp, and the rest only a few primitives
+    unsigned long long cell = ~0ull;
+    if (sc.cand_grid) {
+        const double gx = (A.x - sc.cg_lo[0]) * sc.cg_inv[0], gy = (A.y - sc.cg_lo[1]) * sc.cg_inv[1], gz = (A.z - sc.cg_lo[2]) * sc.cg_inv[2];
+        if (gx >= 0.0 && gy >= 0.0 && gz >= 0.0 && gx < (double)RT_CGRID && gy < (double)RT_CGRID && gz < (double)RT_CGRID) {
+            const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
+            cell = sc.cand_grid[(((size_t)lamp * RT_CGRID + iz) * RT_CGRID + iy) * RT_CGRID + ix];
+        }
+    }
+    if (cell == 0ull) return 0ull;
     double Rl = 0.0;
     if (L.type == RT_LIGHT_SPHERE) Rl = fabs(L.R);
     else if (L.type == RT_LIGHT_SQUARE) Rl = module(d3{L.Dx.x, L.Dx.y, L.Dx.z}) + module(d3{L.Dy.x, L.Dy.y, L.Dy.z});
@@ -764,9 +779,11 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
     for (int k = 0; k < 3; k++) iD[k] = fabs(Da[k]) > 1e-200 ? approx_rcp(Da[k]) : 0.0;
     unsigned long long m = 0;
     for (int j = 0; j < sc.n_prims; j++) {
+        if (__ballot((cell >> j) & 1ull) == 0ull) continue;  // no lane's cell lists this primitive
         const DevGeom RT_CONST& g = GEOM(sc)[j];
-        bool may = true;
-        if (g.type == RT_PRIM_PLANE) {
+        bool may = ((cell >> j) & 1ull) != 0ull;
+        if (!may) {
+        } else if (g.type == RT_PRIM_PLANE) {
             const d3 N = G3(g, PLN_N), Q = G3(g, PLN_NR);
             const double sa = dot(A - Q, N), sl = dot(Lc - Q, N);
             const double tol = 1e-7 * (1.0 + fabs(sa) + fabs(sl));
