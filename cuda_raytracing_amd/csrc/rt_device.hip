@@ -1356,7 +1356,11 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     int sA = s_max;
     while (sA > s_min && blocks * (uint64_t)(64 / sA) < 4 * waves) sA >>= 1;
     const int sB = std::max(s_min, sA / 4), sC = std::max(s_min, sA / 16);
-    const uint32_t bA = (uint32_t)(blocks * 80 / 100), bB = (uint32_t)(blocks * 95 / 100);
+#ifndef RT_PHASE_A
+#define RT_PHASE_A 80
+#define RT_PHASE_B 95
+#endif
+    const uint32_t bA = (uint32_t)(blocks * RT_PHASE_A / 100), bB = (uint32_t)(blocks * RT_PHASE_B / 100);
     const uint64_t tA = (uint64_t)bA * (64 / sA), tB = tA + (uint64_t)(bB - bA) * (64 / sB);
     const uint64_t tasks = tB + (blocks - bB) * (uint64_t)(64 / sC);
     if (tasks >= (1ull << 31)) return rt_fail(RT_ERR_LIMIT, "too many tasks in one call");

@@ -12,4 +12,26 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_sq.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_FLAT --output-format csv -d $OUT/pmc_sq2 -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_sq2.log 2>&1 || echo "pmc_sq2 pass failed (non-fatal)"
-find $OUT -name "*.csv" | head -50
+python3 - $OUT $R <<'PY'
+# summaries worth committing: per-kernel stats and the counters of the render kernel, copied to profiles/<tag>/ by hand
+import csv, glob, json, os, sys
+out, tag = sys.argv[1], sys.argv[2]
+summ = {}
+for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    acc = {}
+    for f in glob.glob(f"{out}/{grp}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "render_kernel" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    summ[grp] = acc
+dst = f"{out}/summary"
+os.makedirs(dst, exist_ok=True)
+json.dump(summ, open(f"{dst}/pmc_render_kernel.json", "w"), indent=1, sort_keys=True)
+for f in glob.glob(f"{out}/trace/*/*_kernel_stats.csv"):
+    open(f"{dst}/kernel_stats.csv", "w").write(open(f).read())
+for line in open(f"{out}/trace.log"):
+    if line.startswith("{"):
+        open(f"{dst}/bench_line.json", "w").write(line)
+print(open(f"{dst}/kernel_stats.csv").read() if os.path.exists(f"{dst}/kernel_stats.csv") else "no kernel stats")
+print(json.dumps(summ, indent=1, sort_keys=True))
+PY
