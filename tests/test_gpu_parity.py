@@ -65,6 +65,9 @@ def test_cpu_ref_mode_against_reference_fixtures(name):
     ("t_bezier", abi.RT_MODE_GPU_REF, 2, True),                                  # stacked-cylinder Bezier
     ("t_bezier", abi.RT_MODE_GPU_REF & ~abi.RT_F_BEZIER_STACKED, 2, True),       # true surface of revolution
     ("c5_final", abi.RT_MODE_GPU_REF & ~abi.RT_F_BEZIER_STACKED, 1, False),
+    ("c2_textured_mirror", abi.RT_MODE_GPU_REF, 8, True),                        # config 2: square light, textured floor, mirror
+    ("c3_orange", abi.RT_MODE_GPU_REF, 2, True),                                 # config 3: glass / mirror balls, cylinders, panels
+    ("c3_orange", abi.RT_MODE_CPU_REF, 1, False),
 ])
 def test_full_render_against_oracle(name, flags, spp, dof):
     hs = scene(name)
