@@ -68,6 +68,9 @@ def test_cpu_ref_mode_against_reference_fixtures(name):
     ("c2_textured_mirror", abi.RT_MODE_GPU_REF, 8, True),                        # config 2: square light, textured floor, mirror
     ("c3_orange", abi.RT_MODE_GPU_REF, 2, True),                                 # config 3: glass / mirror balls, cylinders, panels
     ("c3_orange", abi.RT_MODE_CPU_REF, 1, False),
+    ("t_boxgrid", abi.RT_MODE_GPU_REF, 1, False),   # axis-aligned mesh, rays with a zero direction component, hits on shared edges
+    ("t_boxgrid", abi.RT_MODE_GPU_REF, 3, True),
+    ("t_boxgrid", abi.RT_MODE_CPU_REF, 1, False),
 ])
 def test_full_render_against_oracle(name, flags, spp, dof):
     hs = scene(name)
@@ -85,7 +88,8 @@ def test_full_render_against_oracle(name, flags, spp, dof):
     assert fstats.rays == stats.rays and fstats.nodes_visited <= stats.nodes_visited
 
 
-@pytest.mark.parametrize("name,rect", [("t_icosa", (0, 0, 96, 72)), ("c4_lucy", (60, 30, 40, 24)), ("c5_final", (40, 20, 48, 32))])
+@pytest.mark.parametrize("name,rect", [("t_icosa", (0, 0, 96, 72)), ("c4_lucy", (60, 30, 40, 24)), ("c5_final", (40, 20, 48, 32)),
+                                       ("t_boxgrid", (0, 0, 160, 96))])
 def test_primary_hits_and_visit_order_bit_exact(name, rect):
     """Hit ids and BVH visit order of primary rays, reference-order traversal."""
     hs = scene(name)
