@@ -204,21 +204,26 @@ bool add_face(HostMesh& m, const std::vector<V3>& verts, const int face[3]) {
     return true;
 }
 
-// OBJ subset of CR/primitive.cpp:395-468: "v x y z" and "f a b c" (1-based), everything else ignored.
+// OBJ reader.  What the reference reads (CR/primitive.cpp:395-468: "v x y z" and "f a b c", 1-based, everything
+// else ignored) is read the same way, triangle for triangle.  Forms the reference mis-reads are read as OBJ
+// means them: "a/b/c", "a/b" and "a//c" corners use the vertex index a (the reference stops at the first '/'
+// and builds a degenerate triangle), negative indices count back from the last vertex read so far, polygons
+// are cut into a fan around their first corner (the reference keeps the first three corners only), and lines
+// may be of any length (the reference cuts them at 255 characters).
 bool load_obj(const std::string& path, const Xform& xf, HostMesh& m, std::string& err) {
-    FILE* file = std::fopen(path.c_str(), "r");
+    std::ifstream file(path);
     if (!file) {
         err = "cannot open mesh file " + path;
         return false;
     }
-    char line[256];
     std::vector<V3> verts;
     verts.reserve(50000);
     m.tris.reserve(70000);
     size_t bad = 0;
-    while (std::fgets(line, 256, file)) {
-        std::stringstream ss;
-        ss << line;
+    std::string line;
+    std::vector<int> corners;
+    while (std::getline(file, line)) {
+        std::stringstream ss(line);
         std::string type;
         ss >> type;
         if (type == "v") {
@@ -226,18 +231,28 @@ bool load_obj(const std::string& path, const Xform& xf, HostMesh& m, std::string
             ss >> v.x >> v.y >> v.z;
             add_vertex(m, verts, xf.apply(v));
         } else if (type == "f") {
-            int face[3] = {0, 0, 0};
-            int vertex, i = 0;
-            while (ss >> vertex) {
-                if (i < 3) face[i] = vertex - 1;
-                i++;
+            corners.clear();
+            std::string tok;
+            while (ss >> tok) {
+                char* end = nullptr;
+                long idx = std::strtol(tok.c_str(), &end, 10);
+                if (end == tok.c_str() || (*end != '\0' && *end != '/')) {  // not a corner: the reference stops reading the line here too
+                    break;
+                }
+                corners.push_back(idx < 0 ? (int)((long)verts.size() + idx) : (int)(idx - 1));
             }
-            if (!add_face(m, verts, face)) bad++;
+            if (corners.size() < 3) {
+                bad++;
+                continue;
+            }
+            for (size_t k = 1; k + 1 < corners.size(); k++) {
+                const int face[3] = {corners[0], corners[k], corners[k + 1]};
+                if (!add_face(m, verts, face)) bad++;
+            }
         }
     }
-    std::fclose(file);
     if (bad) {
-        err = "mesh file " + path + " has faces that index missing vertices";
+        err = "mesh file " + path + " has faces with fewer than three corners or with corners that index missing vertices";
         return false;
     }
     return true;
