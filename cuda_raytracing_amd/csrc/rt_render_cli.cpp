@@ -1,6 +1,7 @@
 // Headless command-line renderer: the knobs of the reference's main.cpp (CR/main.cpp:3-18) and of
 // its settings panel (scene, viewport, texture size, samples, depth of field, output name;
 // CR/Renderer.cpp:296-480) as flags.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,12 +13,15 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: rt_render --scene FILE [--assets DIR] [--out FILE.bmp] [--size WxH] [--viewport WxH]\n"
-                 "                 [--spp N] [--dof APERTURE FOCAL] [--seed S] [--mode gpu|cpu] [--strict] [--device D]\n");
+                 "                 [--spp N] [--dof APERTURE FOCAL] [--seed S] [--mode gpu|cpu] [--strict] [--device D]\n"
+                 "                 [--progressive N [--sequence PREFIX]]\n"
+                 "  --progressive N   render the frame as N x N segments, one call each, with a progress line per segment\n"
+                 "  --sequence PREFIX also write PREFIX_0001.bmp, ... after every row of segments\n");
 }
 
 int main(int argc, char** argv) {
-    std::string scene, assets, out = "output.bmp", mode = "gpu";
-    int tw = 1920, th = 1080, vw = 0, vh = 0, spp = 1, device = 0;
+    std::string scene, assets, out = "output.bmp", mode = "gpu", sequence;
+    int tw = 1920, th = 1080, vw = 0, vh = 0, spp = 1, device = 0, progressive = 0;
     bool dof = false, strict = false;
     double aperture = 10, focal = 10;
     unsigned long long seed = 1;
@@ -39,6 +43,8 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--mode")) need(1), mode = argv[++i];
         else if (!std::strcmp(argv[i], "--strict")) strict = true;
         else if (!std::strcmp(argv[i], "--device")) need(1), device = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--progressive")) need(1), progressive = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--sequence")) need(1), sequence = argv[++i];
         else {
             usage();
             return 2;
@@ -58,6 +64,37 @@ int main(int argc, char** argv) {
         r.settings.depthOfField.aperture = aperture;
         r.settings.depthOfField.focalDistance = focal;
         r.outputName = out;
+        if (progressive > 0) {
+            // The reference's per-frame tile mode (CR/Renderer_CUDA.cpp:421-436) with its progress / time-left line
+            // (CR/RayTracer.cu:120-131), to a file sequence instead of a window.
+            r.segmentation = progressive;
+            const auto t0 = std::chrono::steady_clock::now();
+            const int total = progressive * progressive;
+            double rays = 0, kernel_ms = 0;
+            int done = 0, rows = 0;
+            bool more = true;
+            while (more) {
+                more = r.RenderNextSegment();
+                done++;
+                rays += (double)(r.lastStats.rays_primary + r.lastStats.rays_secondary + r.lastStats.rays_shadow);
+                kernel_ms += r.lastStats.kernel_ms;
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                const double frac = done < total ? (double)done / total : 1.0;
+                std::fprintf(stderr, "\rprogress %5.1f%%  elapsed %.2f s  left %.2f s   ", 100.0 * frac, el, el / frac * (1.0 - frac));
+                if (!sequence.empty() && (done % progressive == 0 || !more)) {
+                    char name[32];
+                    std::snprintf(name, sizeof name, "_%04d.bmp", ++rows);
+                    r.outputName = sequence + name;
+                    r.SaveTextureToBMP();
+                }
+            }
+            std::fprintf(stderr, "\n");
+            r.outputName = out;
+            r.SaveTextureToBMP();
+            std::printf("%s: %dx%d, %d spp, %d segments, %.0f rays, kernels %.2f ms (%.1f Mrays/s)\n", out.c_str(), tw, th, spp, done, rays,
+                        kernel_ms, rays / (kernel_ms * 1e3));
+            return 0;
+        }
         r.Render();
         r.SaveTextureToBMP();
         const rt_stats& s = r.lastStats;

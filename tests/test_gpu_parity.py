@@ -249,6 +249,15 @@ def test_headless_cli_and_renderer_class(tmp_path):
     r.RenderInParallel(str(out_py), 4, 1.5, 9.0)
     a, b = out_cli.read_bytes(), out_py.read_bytes()
     assert len(a) == 54 + 96 * 72 * 3 and a == b
+    # segment by segment (the reference's progressive mode): the same frame, plus one file per row of segments
+    out_prog = tmp_path / "prog.bmp"
+    p = subprocess.run([exe, "--scene", os.path.join(SCENES, "t_icosa.txt"), "--assets", os.path.join(ROOT, "assets"), "--out", str(out_prog),
+                        "--size", "96x72", "--spp", "4", "--dof", "1.5", "9", "--seed", "1", "--progressive", "4", "--sequence", str(tmp_path / "seq")],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert out_prog.read_bytes() == a and "progress 100.0%" in p.stderr
+    assert sorted(f.name for f in tmp_path.glob("seq_*.bmp")) == [f"seq_{k:04d}.bmp" for k in range(1, 5)]
+    assert (tmp_path / "seq_0004.bmp").read_bytes() == a and (tmp_path / "seq_0001.bmp").read_bytes() != a
     # a missing scene is an error message and a non-zero exit status, not a crash
     p = subprocess.run([exe, "--scene", "/nonexistent.txt"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "cannot open scene file" in p.stderr
