@@ -1088,13 +1088,28 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
         const double v[3] = {c.x, c.y, c.z};
         for (int k = 0; k < 3; k++) blo[k] = std::fmin(blo[k], v[k] - r), bhi[k] = std::fmax(bhi[k], v[k] + r);
     };
+    // primitives far larger than the rest (walls made of giant spheres, CR/resources/scene_final.txt) are treated like
+    // planes: they do not set the extent of the grid
+    std::vector<double> radii;
+    for (int j = 0; j < d->n_primitives; j++) {
+        const DevGeom& g = geom[j];
+        if (g.type == RT_PRIM_PLANE) continue;
+        if (g.type == RT_PRIM_MESH) {
+            if (g.aux0 != RT_REF_END) radii.push_back(0.5 * g.f[MSH_SCALE] / 3.0);
+        } else if (g.f[BND_R] < 1e100) {
+            radii.push_back(g.f[BND_R]);
+        }
+    }
+    if (radii.empty()) return;
+    std::sort(radii.begin(), radii.end());
+    const double big = 30.0 * radii[radii.size() / 2] + 1e-9;
     for (int j = 0; j < d->n_primitives; j++) {
         const DevGeom& g = geom[j];
         if (g.type == RT_PRIM_PLANE) continue;
         if (g.type == RT_PRIM_MESH) {
             if (g.aux0 == RT_REF_END) continue;
             grow(h3{g.f[MSH_BMIN], g.f[MSH_BMIN + 1], g.f[MSH_BMIN + 2]}, 0), grow(h3{g.f[MSH_BMAX], g.f[MSH_BMAX + 1], g.f[MSH_BMAX + 2]}, 0);
-        } else if (g.f[BND_R] < 1e100) {
+        } else if (g.f[BND_R] < big) {
             grow(h3{g.f[BND_C], g.f[BND_C + 1], g.f[BND_C + 2]}, g.f[BND_R]);
         }
     }
@@ -1110,7 +1125,7 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
     grow(H(d->camera.O), 0);
     for (int k = 0; k < 3; k++) {
         if (!(bhi[k] >= blo[k]) || !std::isfinite(blo[k]) || !std::isfinite(bhi[k])) return;
-        const double ext = std::fmax(bhi[k] - blo[k], 1e-3), pad = 0.25 * ext;
+        const double ext = std::fmax(bhi[k] - blo[k], 1e-3), pad = 0.5 * ext;
         blo[k] -= pad, bhi[k] += pad;
         lo[k] = blo[k];
         inv[k] = RT_CGRID / (bhi[k] - blo[k]);
@@ -1164,6 +1179,11 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                                 if (!(rc2 < rc)) break;
                                 rc = rc2;
                             }
+                        } else if (g.type == RT_PRIM_SPHERE && std::fmax(hmodule(h3{g.f[BND_C], g.f[BND_C + 1], g.f[BND_C + 2]} - A),
+                                                                         hmodule(h3{g.f[BND_C], g.f[BND_C + 1], g.f[BND_C + 2]} - Lc)) +
+                                                                   Rl + rho <
+                                                               g.f[BND_R] * (1.0 - 2e-6) - 2e-9 - 1e-6 * (1.0 + len + rho)) {
+                            may = false;  // the sphere encloses every shadow segment of the cell: its surface lies beyond the lamp
                         } else if (g.f[BND_R] < 1e100) {
                             const bool stretched = g.type == RT_PRIM_MESH || g.type == RT_PRIM_TRIANGLE;
                             const double smax = stretched ? (len + rho + Rl) * (1.0 + 1e-6) : 1.0, rc = stretched ? smax * (Rl + rho) : Rl + rho;

@@ -823,6 +823,13 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
             const d3 e = w - D * sp;
             const double rb = g.f[BND_R], rr = rb + rc, ee = dot(e, e);
             if (ee > rr * rr * (1.0 + 1e-9)) may = false;
+            if (g.type == RT_PRIM_SPHERE) {
+                // a sphere around the whole capsule: every shadow ray starts and ends inside it and meets its surface
+                // only beyond the lamp sample, which is no occlusion (CR/Shade.cu:75: dist - hit.dist > 1e-6)
+                const d3 wl = w - D;  // centre seen from the lamp
+                const double reach = sqrt(fmax(dot(w, w), dot(wl, wl))) + Rl, r_in = rb * (1.0 - 2e-6) - 2e-9 - 1e-6 * (1.0 + len);
+                if (reach < r_in) may = false;
+            }
             if (RT_CONE_BALL && cone && spu > 0.0 && spu <= smax) {
                 // beside the segment: e is the offset of the ball's centre from the axis, and its distance from the
                 // cone's surface is |e| cos(a) - (distance along the axis) sin(a) = |e| cos(a) - spu * Rl

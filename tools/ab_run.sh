@@ -2,7 +2,7 @@
 # Time every library variant in build_ab/ on the headline frame (run on the GPU box).
 for v in "$@"; do
   echo "== $v"
-  RT_AMD_LIB=build_ab/$v.so timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-strict 2>&1 | python -c "
+  RT_AMD_LIB=build_ab/$v.so timeout -k 10 120 python bench.py --scene ${SCENE:-c4_lucy} --steps 3 --warmup 1 --no-cpu-baseline --no-strict 2>&1 | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
