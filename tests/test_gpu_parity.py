@@ -142,11 +142,11 @@ def test_bezier_primary_hits_bit_exact(stacked):
     assert same_double(t, o_t)
 
 
-@pytest.mark.parametrize("spp", [1, 3, 32, 64, 100])
+@pytest.mark.parametrize("spp", [1, 3, 32, 64, 100, 1500])  # 1500: more samples than a wave buffers, summed over two rounds
 def test_sample_counts(spp):
     """1 lane per sample: groups that do not divide 64 and counts above 64 (several passes)."""
     hs = scene("t_icosa")
-    W, H = 40, 24
+    W, H = (40, 24) if spp <= 100 else (9, 5)
     st = orc.settings(spp=spp, dof=True, focal=9.0, aperture=2.0, seed=spp, flags=abi.RT_MODE_GPU_REF)
     ref, _, ostats = orc.render(hs, st, W, H)
     with device_scene(hs) as ds:
@@ -261,3 +261,29 @@ def test_headless_cli_and_renderer_class(tmp_path):
     # a missing scene is an error message and a non-zero exit status, not a crash
     p = subprocess.run([exe, "--scene", "/nonexistent.txt"], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "cannot open scene file" in p.stderr
+
+
+def test_headline_frame_properties():
+    """The bench configuration at full size (c4_lucy, 1920x1080, 32 spp, depth of field): properties that do not need
+    the oracle for the whole frame - the pruned walk gives the strict walk's image and ray counts, the frame does not
+    depend on how it is cut into parts - plus the oracle on a few 16x16 blocks spread over the frame."""
+    hs = scene("c4_lucy")
+    W, H = 1920, 1080
+    st = orc.settings(spp=32, dof=True, focal=1.35, aperture=1.0, seed=1, flags=abi.RT_MODE_GPU_REF)
+    with device_scene(hs) as ds:
+        fast, fstats = ds.render_frame(st, W, H)
+        parts = [ds.render_frame(st, W, H, tile=32, part=k, n_parts=3)[0] for k in range(3)]
+        st.flags |= abi.RT_F_STRICT_TRAVERSAL
+        strict, sstats = ds.render_frame(st, W, H)
+    assert np.array_equal(fast, strict), "pruned traversal changed the full-size frame"
+    assert fstats.rays == sstats.rays and fstats.rays_primary == W * H * 32
+    from cuda_raytracing_amd.distributed import owned_mask
+    whole = np.zeros_like(fast)
+    for k in range(3):
+        m = owned_mask(W, H, 32, k, 3)
+        whole[m] = parts[k][m]
+    assert np.array_equal(whole, fast), "the frame depends on its partition"
+    st.flags = abi.RT_MODE_GPU_REF
+    for (x0, y0) in [(952, 532), (600, 300), (1300, 700), (100, 1000), (1800, 60), (960, 200)]:
+        ref, _, _ = orc.render(hs, st, W, H, rect=(x0, y0, 16, 16))
+        assert_colour_close(fast[y0:y0 + 16, x0:x0 + 16], ref[y0:y0 + 16, x0:x0 + 16], f"block at {x0},{y0}")
