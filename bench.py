@@ -80,7 +80,8 @@ def measured_traffic():
     try:
         sq = j["pmc_sq"]
         extra = {"valu_busy": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * (sq["SQ_WAVES"] / (256 * 4)),
-                 "wave_wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], "valu_insts": sq["SQ_INSTS_VALU"]}
+                 "wave_wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], "valu_insts": sq["SQ_INSTS_VALU"],
+                 "waves_per_simd": sq["SQ_WAVES"] / (256 * 4), "max_waves_per_simd": 8}
     except Exception:
         pass
     return (fetch_kib + write_kib) * 1024.0, {"traffic_note": note, **extra}

@@ -320,6 +320,9 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
         if (surface) {
             const DevShade& m = shade[h.prim];
             need_shade = m.diff > RT_EPS || m.spec > RT_EPS;
+#ifdef RT_ABLATE_SHADING  // timing experiments only: paths without any local shading (same rays, wrong colours)
+            need_shade = false;
+#endif
         }
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);

@@ -42,7 +42,9 @@ enum {
 // with the reference's arithmetic, and a hit is kept only if the reference's own double-precision
 // box tests would have led to that triangle (see mesh_walk4).  Child refs: node4 index, or
 // RT_REF_LEAF | leaf index, or RT_REF_END for an unused slot.
+#ifndef RT_STACK
 #define RT_STACK 32  // per-lane traversal stack entries (LDS); a mesh whose collapsed tree needs more uses the stackless walk
+#endif
 struct DevNode4 {    // 128 bytes
     float lo[3][4], hi[3][4];  // [axis][child]
     uint32_t child[4];
@@ -533,6 +535,9 @@ DEV bool reference_reaches_leaf(const DevScene& sc, uint32_t leaf_index, d3 o, d
 //     tests in double (reference_reaches_leaf);
 //   * ties go to the smaller pre-order index, which is the leaf the reference meets first.
 // Rays whose slab distances do not fit single precision take the stackless double-precision walk.
+#ifndef RT_ANYHIT_SORTED
+#define RT_ANYHIT_SORTED 0
+#endif
 template <bool ANYHIT>
 DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk) {
     const d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
@@ -583,7 +588,7 @@ DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d
                 const bool ok = rf[c] != RT_REF_END && a <= b && !(a > tl) && !(b < 0.0f);
                 key[c] = ok ? a : __builtin_inff();
             }
-            if (!ANYHIT) {  // nearest first
+            if (!ANYHIT || RT_ANYHIT_SORTED) {  // nearest first
 #define RT_CE(i, j)                                                  \
     {                                                                \
         const bool sw = key[j] < key[i];                             \
