@@ -111,7 +111,9 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
         const DevShade& m = shade[h.prim];
         color = D3(m.color);
         m_diff = m.diff, m_spec = m.spec;
+#ifndef RT_ABLATE_TEXTURE  // timing experiments only
         if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, m, h, ctr));
+#endif
         ctr.shaded++;
     }
     RT_LAP(ctr, PF_SHADE_SETUP);
