@@ -318,3 +318,63 @@ def test_other_configs_at_full_size(name, W, H, spp, aperture, focal, blocks):
     for (x0, y0) in blocks:
         ref, _, _ = orc.render(hs, st, W, H, rect=(x0, y0, 8, 8))
         assert_colour_close(whole[y0:y0 + 8, x0:x0 + 8], ref[y0:y0 + 8, x0:x0 + 8], f"{name} block at {x0},{y0}")
+
+
+def test_more_than_64_primitives(tmp_path):
+    """Above 64 primitives the per-lamp candidate masks are off and the shading table stays in global memory."""
+    rng = np.random.default_rng(7)
+    text = ["background\n top= 0.4 0.6 0.9\n bottom= 0.9 0.9 0.8\nend\n",
+            "camera\n O= 0 -14 5\n N= 0 1 -0.3\n lens_W= 1.0\n lens_H= 0.75\n image_W= 96\n image_H= 72\n shade_quality= 0.5\nend\n",
+            "light sphere\n O= 4 -5 9\n R= 0.5\n color= 1 1 1\nend\n", "light point\n O= -6 -4 7\n color= 0.4 0.4 0.5\nend\n",
+            "primitive plane\n N= 0 0 1\n R= 0\n Dx= 3 0 0\n Dy= 0 3 0\n color= 1 1 1\n texture= floor.bmp\n diff= 0.8\n refl= 0.1\nend\n"]
+    for k in range(70):
+        x, y = -7 + 14 * (k % 10) / 9, -3 + 8 * (k // 10) / 6
+        r = 0.25 + 0.3 * rng.random()
+        c = 0.3 + 0.7 * rng.random(3)
+        kind = ["diff= 0.7\n spec= 0.3", "refl= 0.7\n diff= 0.2", "refr= 0.9\n rindex= 1.5\n refl= 0.1"][k % 3]
+        text.append(f"primitive sphere\n O= {x:.3f} {y:.3f} {r:.3f}\n R= {r:.3f}\n color= {c[0]:.3f} {c[1]:.3f} {c[2]:.3f}\n {kind}\nend\n")
+    path = tmp_path / "many.txt"
+    path.write_text("\n".join(text))
+    hs = HostScene(str(path))
+    assert hs.desc.n_primitives > 64
+    W, H = 96, 72
+    st = orc.settings(spp=2, dof=True, focal=14.0, aperture=2.0, seed=3, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
+    ref, _, ostats = orc.render(hs, st, W, H)
+    with device_scene(hs) as ds:
+        img, stats = ds.render_frame(st, W, H)
+        st.flags = abi.RT_MODE_GPU_REF
+        fast, fstats = ds.render_frame(st, W, H)
+    assert_colour_close(img, ref, "70 spheres")
+    assert stats.rays == ostats.rays and fstats.rays == stats.rays
+    assert np.array_equal(fast, img)
+
+
+EDGE_HEAD = "background\n top= 0.2 0.5 0.9\n bottom= 0.9 0.8 0.7\nend\ncamera\n O= 0 -6 1.5\n N= 0 1 -0.1\n image_W= 64\n image_H= 48\nend\n"
+
+
+@pytest.mark.parametrize("body", [
+    "",                                                                                             # nothing but sky
+    "primitive sphere\n O= 0 0 1\n R= 1\n color= 1 0.5 0.2\n diff= 0.8\n refl= 0.3\nend\n",       # geometry, no lamp
+    "light point\n O= 2 -3 5\n color= 1 1 1\nend\n",                                               # a lamp, nothing to light
+    "light sphere\n O= 2 -3 5\n R= 0.4\n color= 1 1 1\nend\nprimitive mesh\n O= 0 0 1\n scale= 1 1 1\n rotation= 0.2 0.1 0\n file= one.obj\n"
+    " color= 0.8 0.8 0.3\n diff= 0.9\nend\nprimitive mesh\n O= 1.5 0.5 1\n scale= 1 1 1\n rotation= 0 0.3 0.2\n file= two.obj\n color= 0.3 0.8 0.8\n"
+    " diff= 0.7\n refl= 0.2\nend\nprimitive plane\n N= 0 0 1\n R= 0\n color= 1 1 1\n diff= 0.8\nend\n",  # one- and two-triangle meshes: no tree to speak of
+], ids=["empty", "no-lamp", "lamp-only", "tiny-meshes"])
+def test_degenerate_scenes(tmp_path, body):
+    (tmp_path / "one.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 0 0 1\nf 1 2 3\n")
+    (tmp_path / "two.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nf 1 2 3\nf 1 3 4\n")
+    (tmp_path / "s.txt").write_text(EDGE_HEAD + body)
+    hs = HostScene(str(tmp_path / "s.txt"), asset_dir=str(tmp_path))
+    W, H = 64, 48
+    st = orc.settings(spp=2, dof=True, focal=6.0, aperture=1.0, seed=9, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
+    ref, _, ostats = orc.render(hs, st, W, H)
+    o_hit, o_t, o_leaf, _, _ = orc.trace_primary(hs, st, W, H)
+    with device_scene(hs) as ds:
+        img, stats = ds.render_frame(st, W, H)
+        hit, t, leaf, _, _ = ds.trace_primary(st, W, H)
+        st.flags = abi.RT_MODE_GPU_REF
+        fast, _ = ds.render_frame(st, W, H)
+    assert np.array_equal(hit, o_hit) and np.array_equal(leaf, o_leaf) and same_double(t, o_t)
+    assert_colour_close(img, ref, "degenerate scene")
+    assert stats.rays == ostats.rays
+    assert np.array_equal(fast, img)
