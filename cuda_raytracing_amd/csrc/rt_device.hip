@@ -173,6 +173,20 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             const uint32_t opix = __shfl(pixel, owner, 64), osmp = __shfl(smp, owner, 64), odraw = __shfl(draw, owner, 64);
             const unsigned long long ocand = STRICT ? ~0ull : __shfl(cand, owner, 64);
             bool clear = false;
+#ifdef RT_UTIL_COUNTERS
+            if (act && !STRICT) {  // which kinds of primitives make this ray necessary
+                bool k0 = false, k1 = false, k2 = false;
+                for (int j = 0; j < sc.n_prims && j < 64; j++) {
+                    if (!((ocand >> j) & 1ull)) continue;
+                    const int ty = GEOM(sc)[j].type;
+                    if (ty == RT_PRIM_MESH) k2 = true;
+                    else if (ty == RT_PRIM_CYLINDER || ty == RT_PRIM_BEZIER) k1 = true;
+                    else k0 = true;
+                }
+                ctr.u[6] += k0, ctr.u[8] += k1, ctr.u[10] += k2;
+                ctr.u[7] += (k0 && !k1 && !k2), ctr.u[9] += (k1 && !k0 && !k2), ctr.u[11] += (k2 && !k0 && !k1);
+            }
+#endif
             RT_LAP(ctr, PF_CHUNK_SHFL);
             if (act) {
                 d3 target = d3{L.O.x, L.O.y, L.O.z};
@@ -695,6 +709,7 @@ static void cylinder_geom(DevGeom& g, hostmath::h3 O1, hostmath::h3 O2, double R
     put(g, CYL_NBOT, hunit(O2 - O1));
     double half = 0.5 * hmodule(dd);
     set_ball(g, (O1 + O2) * 0.5, std::sqrt(half * half + R * R));
+    g.f[CAP_R] = std::fabs(R) * (1.0 + 1e-6) + 1e-9;  // with CYL_O1, CYL_O2 (= CAP_P0, CAP_P1): the bounding capsule
 }
 
 // ---- four-wide tree of the pruned walk (DevNode4) -------------------------------------------------
@@ -1041,6 +1056,10 @@ static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g
             if (tmax >= tmin) {
                 double half = 0.5 * (tmax - tmin);
                 set_ball(g, O1 + axis * (0.5 * (tmin + tmax)), std::sqrt(half * half + rmax * rmax));
+                put(g, CAP_P0, O1 + axis * tmin), put(g, CAP_P1, O1 + axis * tmax);
+                g.f[CAP_R] = rmax * (1.0 + 1e-6) + 1e-9;
+            } else {
+                g.f[CAP_R] = 1e300;  // nothing known: never pruned by the capsule
             }
             break;
         }
@@ -1075,6 +1094,21 @@ static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g
         }
         default: break;
     }
+}
+
+// squared distance between two segments (host twin of seg_seg_dist2)
+static double host_seg_seg_dist2(hostmath::h3 p1, hostmath::h3 q1, hostmath::h3 p2, hostmath::h3 q2) {
+    using namespace hostmath;
+    const h3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const double a = hdot(d1, d1), e = hdot(d2, d2), f = hdot(d2, r), c = hdot(d1, r), b = hdot(d1, d2);
+    const double tiny = 1e-200, denom = a * e - b * b;
+    double s = (denom > 1e-12 * a * e && denom > tiny) ? std::fmin(std::fmax((b * f - c * e) / denom, 0.0), 1.0) : 0.0;
+    if (!(a > tiny)) s = 0.0;
+    double t = e > tiny ? (b * s + f) / e : 0.0;
+    if (t < 0.0) t = 0.0, s = a > tiny ? std::fmin(std::fmax(-c / a, 0.0), 1.0) : 0.0;
+    else if (t > 1.0) t = 1.0, s = a > tiny ? std::fmin(std::fmax((b - c) / a, 0.0), 1.0) : 0.0;
+    const h3 g = (p1 + d1 * s) - (p2 + d2 * t);
+    return hdot(g, g);
 }
 
 // ---- candidate grid: which primitives can stand between a cell's points and a lamp -------------------
@@ -1198,6 +1232,11 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                             const h3 e = w - D * sp;
                             const double rr = g.f[BND_R] + rc;
                             if (hdot(e, e) > rr * rr * (1.0 + 1e-9)) may = false;
+                            if (may && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER) && g.f[CAP_R] < 1e100) {
+                                const double reach = g.f[CAP_R] + Rl + rho + 1e-9 * (1.0 + len);
+                                const h3 P0{g.f[CAP_P0], g.f[CAP_P0 + 1], g.f[CAP_P0 + 2]}, P1{g.f[CAP_P1], g.f[CAP_P1 + 1], g.f[CAP_P1 + 2]};
+                                if (host_seg_seg_dist2(A, Lc, P0, P1) > reach * reach * (1.0 + 1e-6)) may = false;
+                            }
                         }
                         if (may) m |= 1ull << j;
                     }
@@ -1450,7 +1489,9 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     for (int k = 0; k < PF_COUNT; k++) tot += c[CTR_ALL + k];
     for (int k = 0; k < PF_COUNT; k++)
         std::fprintf(stderr, "[time] %-26s %5.1f%%\n", sect[k], 100.0 * c[CTR_ALL + k] / (double)(tot ? tot : 1));
-    for (int k = 0; k < 6; k++) {
+    std::fprintf(stderr, "[util] shadow rays traced because of: sphere/plane/square %llu (only: %llu), cylinder/bezier %llu (only: %llu), mesh %llu (only: %llu)\n",
+                 c[CTR_U_PROBES + 6], c[CTR_U_PROBES + 7], c[CTR_U_PROBES + 8], c[CTR_U_PROBES + 9], c[CTR_U_PROBES + 10], c[CTR_U_PROBES + 11]);
+    for (int k = 0; k < 3; k++) {
         const unsigned long long lanes = c[CTR_U_PROBES + 2 * k], slots = c[CTR_U_PROBES + 2 * k + 1];
         std::fprintf(stderr, "[util] %-24s lanes %.1f%% (%llu lane executions, %llu wave executions)\n", probe_name[k],
                      100.0 * lanes / (double)(slots ? slots : 1), lanes, slots / 64);

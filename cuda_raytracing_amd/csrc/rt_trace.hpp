@@ -32,7 +32,8 @@ enum {
     CYL_O1 = 0, CYL_O2 = 3, CYL_DN = 6, CYL_LEN = 9, CYL_R2 = 10, CYL_NTOP = 11, CYL_NBOT = 14,
     TRI_V1 = 0, TRI_E1 = 3, TRI_E2 = 6, TRI_N = 9,
     MSH_SCALE = 0, MSH_BMIN = 1, MSH_BMAX = 4,                          // culling scale, root box (= the root node's box)
-    BND_C = 17, BND_R = 20                                              // bounding ball (cylinder, bezier, segments)
+    BND_C = 17, BND_R = 20,                                             // bounding ball (cylinder, bezier, segments)
+    CAP_P0 = 0, CAP_P1 = 3, CAP_R = 21                                  // bounding capsule of a cylinder / Bezier primitive: axis segment, radius
 };
 
 // Node of the pruned walk: the binary tree of the reference collapsed two levels at a time, so a
@@ -123,8 +124,10 @@ enum { PF_TASK = 0, PF_FRAME, PF_CLOSEST_PRIMS, PF_CLOSEST_MESH, PF_SHADE_SETUP,
 #ifdef RT_UTIL_COUNTERS
 #define RT_PROBE(ctr, k)                                                                            \
     do {                                                                                            \
-        (ctr).u[2 * (k)]++;                                                                         \
-        if (lane_id() == (int)__ffsll((long long)__ballot(true)) - 1) (ctr).u[2 * (k) + 1] += 64u;  \
+        if ((k) < 3) {                                                                              \
+            (ctr).u[2 * (k)]++;                                                                     \
+            if (lane_id() == (int)__ffsll((long long)__ballot(true)) - 1) (ctr).u[2 * (k) + 1] += 64u; \
+        }                                                                                           \
     } while (0)
 // RT_LAP(ctr, s): the time since the previous lap of this wave is charged to section s
 #define RT_LAP(ctr, s)                                                                              \
@@ -745,6 +748,23 @@ DEV double approx_rsqrt(double x) {
     return __builtin_fma(y, __builtin_fma(-h, y, 0.5), y);
 }
 
+// squared distance between the segments p1..q1 and p2..q2 (closest points by the usual clamped solve); good to
+// ~1e-12 of the lengths involved, which the callers' margins cover
+DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2) {
+    const d3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const double a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
+    const double tiny = 1e-200;
+    const double ia = a > tiny ? approx_rcp(a) : 0.0, ie = e > tiny ? approx_rcp(e) : 0.0;
+    const double denom = a * e - b * b;
+    double s = denom > 1e-12 * a * e && denom > tiny ? fmin(fmax((b * f - c * e) * approx_rcp(denom), 0.0), 1.0) : 0.0;
+    if (!(a > tiny)) s = 0.0;
+    double t = (b * s + f) * ie;
+    if (t < 0.0) t = 0.0, s = fmin(fmax(-c * ia, 0.0), 1.0);
+    else if (t > 1.0) t = 1.0, s = fmin(fmax((b - c) * ia, 0.0), 1.0);
+    const d3 g = (p1 + d1 * s) - (p2 + d2 * t);
+    return dot(g, g);
+}
+
 #ifndef RT_CONE_MESH_PASSES
 #define RT_CONE_MESH_PASSES 2
 #endif
@@ -834,6 +854,11 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
                 const d3 wl = w - D;  // centre seen from the lamp
                 const double reach = sqrt(fmax(dot(w, w), dot(wl, wl))) + Rl, r_in = rb * (1.0 - 2e-6) - 2e-9 - 1e-6 * (1.0 + len);
                 if (reach < r_in) may = false;
+            }
+            if (may && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER)) {
+                // long thin primitives: their bounding ball is mostly empty, the capsule around their axis is not
+                const double reach = g.f[CAP_R] + Rl + 1e-9 * (1.0 + len);
+                if (seg_seg_dist2(A, Lc, G3(g, CAP_P0), G3(g, CAP_P1)) > reach * reach * (1.0 + 1e-6)) may = false;
             }
             if (RT_CONE_BALL && cone && spu > 0.0 && spu <= smax) {
                 // beside the segment: e is the offset of the ball's centre from the axis, and its distance from the
