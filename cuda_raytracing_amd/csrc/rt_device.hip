@@ -138,10 +138,12 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             if (!(dt > RT_EPS)) {
                 work = false;
             } else {
-                cand = light_candidates(sc, P.flags, h.C, L, l);
+                unsigned long long full;
+                cand = light_candidates(sc, P.flags, h.C, L, l, full);
                 if (P.flags & RT_F_SHADOW_SELF_SKIP) cand &= ~(h.prim < 64 ? 1ull << h.prim : 0ull);
                 if (L.light_primitive >= 0 && L.light_primitive < 64) cand &= ~(1ull << L.light_primitive);
                 if (cand == 0ull) work = false, cnt = n_l;
+                else if ((full & cand) != 0ull) work = false, cnt = 0;  // in the umbra of one primitive: no sample is visible
             }
         }
         RT_LAP(ctr, PF_CAND);

@@ -750,7 +750,7 @@ DEV double approx_rsqrt(double x) {
 
 // squared distance between the segments p1..q1 and p2..q2 (closest points by the usual clamped solve); good to
 // ~1e-12 of the lengths involved, which the callers' margins cover
-DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2) {
+DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2, double& s_out, double& t_out) {
     const d3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
     const double a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
     const double tiny = 1e-200;
@@ -762,6 +762,7 @@ DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2) {
     if (t < 0.0) t = 0.0, s = fmin(fmax(-c * ia, 0.0), 1.0);
     else if (t > 1.0) t = 1.0, s = fmin(fmax((b - c) * ia, 0.0), 1.0);
     const d3 g = (p1 + d1 * s) - (p2 + d2 * t);
+    s_out = s, t_out = t;
     return dot(g, g);
 }
 
@@ -771,7 +772,10 @@ DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2) {
 #ifndef RT_CONE_BALL
 #define RT_CONE_BALL 1
 #endif
-DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp) {
+// `full` gets the primitives that, each on its own, hide the whole lamp from A (spheres and cylinders only: the
+// point lies in their umbra, every sample is occluded, none needs tracing).
+DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp, unsigned long long& full) {
+    full = 0ull;
     if (sc.n_prims > 64) return ~0ull;
     // the cell's mask first: most points have nothing near their way to the lamp, and the rest only a few primitives
     unsigned long long cell = ~0ull;
@@ -858,7 +862,33 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
             if (may && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER)) {
                 // long thin primitives: their bounding ball is mostly empty, the capsule around their axis is not
                 const double reach = g.f[CAP_R] + Rl + 1e-9 * (1.0 + len);
-                if (seg_seg_dist2(A, Lc, G3(g, CAP_P0), G3(g, CAP_P1)) > reach * reach * (1.0 + 1e-6)) may = false;
+                const d3 P0 = G3(g, CAP_P0), P1 = G3(g, CAP_P1);
+                double ss, tt;
+                const double dd2 = seg_seg_dist2(A, Lc, P0, P1, ss, tt);
+                if (dd2 > reach * reach * (1.0 + 1e-6)) may = false;
+                if (may && g.type == RT_PRIM_CYLINDER) {
+                    // Umbra of the solid cylinder: the axis of the shadow rays passes so deep inside it (radially and away
+                    // from both ends) that every ray to the lamp goes through its interior, all of it lies nearer than the
+                    // lamp, and A is outside: CR/Collision.cu:3-107 then reports a hit in front of the lamp for every sample.
+                    const double Rc = g.f[CAP_R] * (1.0 - 2e-6) - 2e-9, alen = g.f[CYL_LEN];
+                    const double m = Rl + 1e-5 * (1.0 + alen + Rc);
+                    const d3 a0 = A - P0, a1 = A - P1, ax = G3(g, CYL_DN);
+                    const double ta = fmin(fmax(dot(a0, ax), 0.0), alen);
+                    const d3 ea = a0 - ax * ta;
+                    const double far2 = fmax(dot(a0, a0), dot(a1, a1));
+                    const double lim = len - Rl - 2e-6 - g.f[CAP_R];
+                    const double deep = Rc - Rl - 1e-6;
+                    if (tt * alen > m && (1.0 - tt) * alen > m && deep > 0.0 && dd2 < deep * deep * (1.0 - 1e-6) && lim > 0.0 &&
+                        far2 < lim * lim * (1.0 - 1e-6) && dot(ea, ea) > (g.f[CAP_R] + 2e-6) * (g.f[CAP_R] + 2e-6) * (1.0 + 1e-6))
+                        full |= 1ull << j;
+                }
+            }
+            if (may && g.type == RT_PRIM_SPHERE) {
+                // Umbra of a sphere (CR/Collision.cu:155-176): every ray to the lamp passes its centre at less than the radius
+                // (with 1e-6 to spare in the discriminant), the sphere lies wholly in front of the lamp, A wholly outside
+                const double r_lo = rb * (1.0 - 2e-6) - 2e-9, dA2 = dot(w, w);
+                const double dA = dA2 * approx_rsqrt(fmax(dA2, 1e-300)), dline = ee * approx_rsqrt(fmax(ee, 1e-300)) + Rl;
+                if (r_lo * r_lo - dline * dline > 2e-6 * (1.0 + r_lo * r_lo) && dA + rb < len - Rl - 2e-6 && dA - rb > 2e-6) full |= 1ull << j;
             }
             if (RT_CONE_BALL && cone && spu > 0.0 && spu <= smax) {
                 // beside the segment: e is the offset of the ball's centre from the axis, and its distance from the
