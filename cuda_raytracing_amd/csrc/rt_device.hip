@@ -138,10 +138,10 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             if (!(dt > RT_EPS)) {
                 work = false;
             } else {
-                unsigned long long full;
-                cand = light_candidates(sc, P.flags, h.C, L, l, full);
-                if (P.flags & RT_F_SHADOW_SELF_SKIP) cand &= ~(h.prim < 64 ? 1ull << h.prim : 0ull);
-                if (L.light_primitive >= 0 && L.light_primitive < 64) cand &= ~(1ull << L.light_primitive);
+                unsigned long long full, skip = 0ull;  // primitives the shadow test leaves out for this point and lamp
+                if ((P.flags & RT_F_SHADOW_SELF_SKIP) && h.prim < 64) skip |= 1ull << h.prim;
+                if (L.light_primitive >= 0 && L.light_primitive < 64) skip |= 1ull << L.light_primitive;
+                cand = light_candidates(sc, P.flags, h.C, L, l, skip, full) & ~skip;
                 if (cand == 0ull) work = false, cnt = n_l;
                 else if ((full & cand) != 0ull) work = false, cnt = 0;  // in the umbra of one primitive: no sample is visible
             }
@@ -1099,7 +1099,7 @@ static void build_geom(const rt_scene_desc* d, const rt_primitive& p, DevGeom& g
 }
 
 // squared distance between two segments (host twin of seg_seg_dist2)
-static double host_seg_seg_dist2(hostmath::h3 p1, hostmath::h3 q1, hostmath::h3 p2, hostmath::h3 q2) {
+static double host_seg_seg_dist2(hostmath::h3 p1, hostmath::h3 q1, hostmath::h3 p2, hostmath::h3 q2, double& s_out, double& t_out) {
     using namespace hostmath;
     const h3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
     const double a = hdot(d1, d1), e = hdot(d2, d2), f = hdot(d2, r), c = hdot(d1, r), b = hdot(d1, d2);
@@ -1110,6 +1110,7 @@ static double host_seg_seg_dist2(hostmath::h3 p1, hostmath::h3 q1, hostmath::h3 
     if (t < 0.0) t = 0.0, s = a > tiny ? std::fmin(std::fmax(-c / a, 0.0), 1.0) : 0.0;
     else if (t > 1.0) t = 1.0, s = a > tiny ? std::fmin(std::fmax((b - c) / a, 0.0), 1.0) : 0.0;
     const h3 g = (p1 + d1 * s) - (p2 + d2 * t);
+    s_out = s, t_out = t;
     return hdot(g, g);
 }
 
@@ -1175,7 +1176,7 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
     // a cell's points are those whose computed index is this cell: allow for the rounding of the index arithmetic
     const double rho = 0.5 * std::sqrt(cell[0] * cell[0] + cell[1] * cell[1] + cell[2] * cell[2]) * (1.0 + 1e-6) + 1e-9;
     const size_t per_lamp = (size_t)RT_CGRID * RT_CGRID * RT_CGRID;
-    grid.assign(per_lamp * d->n_lights, 0ull);
+    grid.assign(per_lamp * d->n_lights * 2, 0ull);  // per cell: [may occlude, occludes every sample]
     for (int l = 0; l < d->n_lights; l++) {
         const h3 Lc = H(d->lights[l].O);
         const double Rl = lamp_r[l];
@@ -1185,10 +1186,10 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                     const h3 A{lo[0] + (ix + 0.5) * cell[0], lo[1] + (iy + 0.5) * cell[1], lo[2] + (iz + 0.5) * cell[2]};
                     const h3 D = Lc - A;
                     const double L2 = hdot(D, D), len = std::sqrt(L2);
-                    unsigned long long m = 0;
+                    unsigned long long m = 0, mfull = 0;
                     for (int j = 0; j < d->n_primitives; j++) {
                         const DevGeom& g = geom[j];
-                        bool may = true;
+                        bool may = true, full = false;
                         if (!(L2 > 1e-200)) {
                         } else if (g.type == RT_PRIM_PLANE) {
                             const h3 N{g.f[PLN_N], g.f[PLN_N + 1], g.f[PLN_N + 2]}, Q{g.f[PLN_NR], g.f[PLN_NR + 1], g.f[PLN_NR + 2]};
@@ -1237,12 +1238,34 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                             if (may && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER) && g.f[CAP_R] < 1e100) {
                                 const double reach = g.f[CAP_R] + Rl + rho + 1e-9 * (1.0 + len);
                                 const h3 P0{g.f[CAP_P0], g.f[CAP_P0 + 1], g.f[CAP_P0 + 2]}, P1{g.f[CAP_P1], g.f[CAP_P1 + 1], g.f[CAP_P1 + 2]};
-                                if (host_seg_seg_dist2(A, Lc, P0, P1) > reach * reach * (1.0 + 1e-6)) may = false;
+                                double ss, tt;
+                                const double dd2 = host_seg_seg_dist2(A, Lc, P0, P1, ss, tt);
+                                if (dd2 > reach * reach * (1.0 + 1e-6)) may = false;
+                                if (may && g.type == RT_PRIM_CYLINDER) {  // umbra of the cylinder for every point of the cell (see light_candidates)
+                                    const double Rc = g.f[CAP_R] * (1.0 - 2e-6) - 2e-9, alen = g.f[CYL_LEN];
+                                    const double mrg = Rl + rho + 1e-5 * (1.0 + alen + Rc);
+                                    const h3 ax{g.f[CYL_DN], g.f[CYL_DN + 1], g.f[CYL_DN + 2]}, a0 = A - P0, a1 = A - P1;
+                                    const double ta = std::fmin(std::fmax(hdot(a0, ax), 0.0), alen);
+                                    const h3 ea = a0 - ax * ta;
+                                    const double far = std::sqrt(std::fmax(hdot(a0, a0), hdot(a1, a1))) + rho;
+                                    const double lim = len - rho - Rl - 2e-6 - g.f[CAP_R], deep = Rc - Rl - rho - 1e-6;
+                                    if (tt * alen > mrg && (1.0 - tt) * alen > mrg && deep > 0.0 && dd2 < deep * deep * (1.0 - 1e-6) && lim > 0.0 && far < lim * (1.0 - 1e-6) &&
+                                        std::sqrt(hdot(ea, ea)) - rho > (g.f[CAP_R] + 2e-6) * (1.0 + 1e-6))
+                                        full = true;
+                                }
+                            }
+                            if (may && g.type == RT_PRIM_SPHERE) {  // umbra of the sphere for every point of the cell
+                                const double rb = g.f[BND_R], r_lo = rb * (1.0 - 2e-6) - 2e-9, dA = hmodule(w);
+                                const double dline = std::sqrt(hdot(e, e)) + Rl + rho;
+                                if (r_lo * r_lo - dline * dline > 2e-6 * (1.0 + r_lo * r_lo) && dline < r_lo && dA + rho + rb < len - rho - Rl - 2e-6 && dA - rho - rb > 2e-6)
+                                    full = true;
                             }
                         }
                         if (may) m |= 1ull << j;
+                        if (may && full) mfull |= 1ull << j;
                     }
-                    grid[((size_t)l * RT_CGRID + iz) * RT_CGRID * RT_CGRID + (size_t)iy * RT_CGRID + ix] = m;
+                    const size_t cell = ((size_t)l * RT_CGRID + iz) * RT_CGRID * RT_CGRID + (size_t)iy * RT_CGRID + ix;
+                    grid[2 * cell] = m, grid[2 * cell + 1] = mfull;
                 }
     }
 }

@@ -774,7 +774,8 @@ DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2, double& s_out, double& t_ou
 #endif
 // `full` gets the primitives that, each on its own, hide the whole lamp from A (spheres and cylinders only: the
 // point lies in their umbra, every sample is occluded, none needs tracing).
-DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp, unsigned long long& full) {
+DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp, unsigned long long skip,
+                                        unsigned long long& full) {
     full = 0ull;
     if (sc.n_prims > 64) return ~0ull;
     // the cell's mask first: most points have nothing near their way to the lamp, and the rest only a few primitives
@@ -783,7 +784,12 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
         const double gx = (A.x - sc.cg_lo[0]) * sc.cg_inv[0], gy = (A.y - sc.cg_lo[1]) * sc.cg_inv[1], gz = (A.z - sc.cg_lo[2]) * sc.cg_inv[2];
         if (gx >= 0.0 && gy >= 0.0 && gz >= 0.0 && gx < (double)RT_CGRID && gy < (double)RT_CGRID && gz < (double)RT_CGRID) {
             const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
-            cell = sc.cand_grid[(((size_t)lamp * RT_CGRID + iz) * RT_CGRID + iy) * RT_CGRID + ix];
+            const ulonglong2 cm = reinterpret_cast<const ulonglong2*>(sc.cand_grid)[(((size_t)lamp * RT_CGRID + iz) * RT_CGRID + iy) * RT_CGRID + ix];
+            cell = cm.x & ~skip;
+            if ((cm.y & ~skip) != 0ull) {  // the whole cell lies in the umbra of one primitive
+                full = cm.y;
+                return cell;
+            }
         }
     }
     if (cell == 0ull) return 0ull;
@@ -808,7 +814,7 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
     for (int k = 0; k < 3; k++) iD[k] = fabs(Da[k]) > 1e-200 ? approx_rcp(Da[k]) : 0.0;
     unsigned long long m = 0;
     for (int j = 0; j < sc.n_prims; j++) {
-        if (__ballot((cell >> j) & 1ull) == 0ull) continue;  // no lane's cell lists this primitive
+        if (__ballot(((cell >> j) & 1ull) != 0ull && (full & ~skip) == 0ull) == 0ull) continue;  // no lane still needs this primitive
         const DevGeom RT_CONST& g = GEOM(sc)[j];
         bool may = ((cell >> j) & 1ull) != 0ull;
         if (!may) {
