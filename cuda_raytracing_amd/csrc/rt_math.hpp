@@ -31,6 +31,26 @@ DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 DEV d3 cross(d3 a, d3 b) { return d3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 DEV double module(d3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
 DEV d3 unit(d3 a) { return a / module(a); }
+// atan2 for texture coordinates: the quotient of the smaller by the larger magnitude, folded once more around
+// tan(pi/8), then the odd polynomial fdlibm's atan uses below 7/16 (its coefficients), and the octant put back.
+// A few ulp from a correctly rounded atan2 - texture coordinates are on the colour path - at a fraction of the
+// instructions and registers of the general library routine, which this kernel cannot afford.
+DEV double rt_atan2(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y), mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double a = mx > 0.0 ? mn / mx : 0.0;
+    const bool big = a > 0.41421356237309503;
+    const double t = big ? (a - 1.0) / (a + 1.0) : a;
+    const double z = t * t, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    double r = t - t * (s1 + s2);
+    if (big) r = 7.85398163397448278999e-01 + (r + 3.06161699786838301793e-17);
+    if (ay > ax) r = 1.57079632679489655800e+00 - r;
+    if (x < 0.0) r = 3.14159265358979311600e+00 - r;
+    return y < 0.0 ? -r : r;
+}
 DEV d3 vertical(d3 a) {
     d3 r = cross(a, D3(0, 0, 1));
     if (fabs(r.x) < RT_EPS && fabs(r.y) < RT_EPS && fabs(r.z) < RT_EPS) return D3(1, 0, 0);

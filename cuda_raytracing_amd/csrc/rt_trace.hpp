@@ -1022,6 +1022,11 @@ DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevShade& px, doub
 DEV d3 T3(const DevShade& p, int i) { return d3{p.tf[i], p.tf[i + 1], p.tf[i + 2]}; }
 DEV d3 texture_color(const DevScene& sc, uint32_t flags, const DevShade& p, const Hit& c, Counters& ctr) {
     double u, v;
+#ifdef RT_ABLATE_UV  // timing experiments only: 1 = no sphere / cylinder mapping, 2 = no sphere, 3 = no cylinder
+    if (RT_ABLATE_UV == 1 && p.type != RT_PRIM_PLANE) return D3(0.5, 0.5, 0.5);
+    if (RT_ABLATE_UV == 2 && p.type == RT_PRIM_SPHERE) return D3(0.5, 0.5, 0.5);
+    if (RT_ABLATE_UV == 3 && p.type == RT_PRIM_CYLINDER) return D3(0.5, 0.5, 0.5);
+#endif
     switch (p.type) {
         case RT_PRIM_SPHERE: {
             d3 I = unit(c.C - T3(p, TF_SPH_O));
@@ -1046,7 +1051,11 @@ DEV d3 texture_color(const DevScene& sc, uint32_t flags, const DevShade& p, cons
             d3 O1 = T3(p, TF_CYL_O1), O2 = T3(p, TF_CYL_O2);
             if (!c.front) {
                 d3 cp = c.C - O1;
-                double ang = atan2(cp.z, cp.x);
+#ifdef RT_ABLATE_ATAN2  // timing experiments only
+                double ang = cp.z * 0.1 + cp.x * 0.2;
+#else
+                double ang = rt_atan2(cp.z, cp.x);  // atan2 of CR/Primitive.cu:58, see rt_atan2
+#endif
                 if (ang < 0) ang += 2 * M_PI;
                 u = ang / (2 * M_PI);
                 v = dot(c.C - O1, T3(p, TF_CYL_AX)) / p.tf[TF_CYL_LEN];
@@ -1062,6 +1071,9 @@ DEV d3 texture_color(const DevScene& sc, uint32_t flags, const DevShade& p, cons
             return D3(0, 0, 0);
     }
     ctr.texfetch++;
+#ifdef RT_ABLATE_TEXFETCH  // timing experiments only
+    return D3(u - floor(u), v - floor(v), 0.5);
+#endif
     return smooth_color(sc, flags, p, u, v);
 }
 
