@@ -416,7 +416,7 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                     contrib = result * m.refr;
                 } else {
                     d3 ab = D3(m.absor) * -f_dist[k];
-                    d3 tr = D3(exp(ab.x), exp(ab.y), exp(ab.z));
+                    d3 tr = D3(rt_exp(ab.x), rt_exp(ab.y), rt_exp(ab.z));
                     contrib = mulv(result, tr) * m.refr;
                 }
                 d3 acc = D3(f_acc[k][0], f_acc[k][1], f_acc[k][2]) + contrib;

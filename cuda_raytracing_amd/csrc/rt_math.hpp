@@ -51,6 +51,33 @@ DEV double rt_atan2(double y, double x) {
     if (x < 0.0) r = 3.14159265358979311600e+00 - r;
     return y < 0.0 ? -r : r;
 }
+// acos and exp of the colour path, written out (fdlibm's rational / polynomial kernels, an ulp or two from
+// correctly rounded) for the same reason as rt_atan2: the general library routines are too large for this kernel.
+DEV double rt_asin_kernel(double z) {  // (asin(x) - x) / x for z = x*x <= 1/4
+    const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 +
+                     z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+    const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 +
+                     z * 7.70381505559019352791e-02)));
+    return p / q;
+}
+DEV double rt_acos(double x) {  // |x| <= 1
+    const double ax = fabs(x);
+    if (ax < 0.5) return 1.57079632679489655800e+00 - (x + x * rt_asin_kernel(x * x)) + 6.12323399573676603587e-17;
+    const double z = fmax((1.0 - ax) * 0.5, 0.0), s = sqrt(z);
+    const double a = 2.0 * (s + s * rt_asin_kernel(z));
+    return x > 0.0 ? a : 3.14159265358979311600e+00 - a;
+}
+DEV double rt_exp(double x) {
+    if (x < -745.0) return 0.0;
+    if (!(x <= 709.0)) return x != x ? x : __builtin_inf();
+    const double k = floor(x * 1.44269504088896338700e+00 + 0.5);
+    const double hi = x - k * 6.93147180369123816490e-01, lo = k * 1.90821492927058770002e-10;
+    const double r = hi - lo, t = r * r;
+    const double c = r - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 +
+                     t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, (int)k);
+}
 DEV d3 vertical(d3 a) {
     d3 r = cross(a, D3(0, 0, 1));
     if (fabs(r.x) < RT_EPS && fabs(r.y) < RT_EPS && fabs(r.z) < RT_EPS) return D3(1, 0, 0);

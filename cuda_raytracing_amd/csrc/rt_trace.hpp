@@ -1030,8 +1030,10 @@ DEV d3 texture_color(const DevScene& sc, uint32_t flags, const DevShade& p, cons
     switch (p.type) {
         case RT_PRIM_SPHERE: {
             d3 I = unit(c.C - T3(p, TF_SPH_O));
-            double a = acos(-dot(I, T3(p, TF_SPH_DE)));
-            double b = acos(fmin(fmax(dot(I, T3(p, TF_SPH_DC)) / sin(a), -1.0), 1.0));
+            // acos / sin of CR/Primitive.cu:24-33 through the compact routines; sin(acos(x)) as sqrt(1 - x^2)
+            const double x = fmin(fmax(-dot(I, T3(p, TF_SPH_DE)), -1.0), 1.0);
+            double a = rt_acos(x);
+            double b = rt_acos(fmin(fmax(dot(I, T3(p, TF_SPH_DC)) / sqrt(1.0 - x * x), -1.0), 1.0));
             u = a / M_PI, v = b / 2 / M_PI;
             if (dot(I, T3(p, TF_SPH_X)) < 0) v = 1 - v;
             break;
