@@ -56,7 +56,9 @@ struct DevNode4 {    // 128 bytes
 // and the frame the texture coordinates are taken in, with the ray-independent parts of
 // CR/Primitive.cu:16-83 computed once on the host (same IEEE operations).  The kernel keeps the table
 // in LDS when the scene has at most RT_SHADE_LDS primitives.
+#ifndef RT_CGRID
 #define RT_CGRID 64
+#endif
 #define RT_SHADE_LDS 64
 struct DevShade {  // 216 bytes
     double color[3], absor[3], diff, spec, refl, refr, rindex, drefl;
