@@ -356,10 +356,12 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                 if (has_refl || has_refr) {
                     const int k = sp;
                     f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
-                    f_C[k][0] = h.C.x, f_C[k][1] = h.C.y, f_C[k][2] = h.C.z;
-                    f_N[k][0] = h.N.x, f_N[k][1] = h.N.y, f_N[k][2] = h.N.z;
-                    f_V[k][0] = d.x, f_V[k][1] = d.y, f_V[k][2] = d.z;
-                    f_dist[k] = h.dist;
+                    if (has_refl && has_refr) {  // only a refraction that waits for the reflection subtree needs the hit again
+                        f_C[k][0] = h.C.x, f_C[k][1] = h.C.y, f_C[k][2] = h.C.z;
+                        f_N[k][0] = h.N.x, f_N[k][1] = h.N.y, f_N[k][2] = h.N.z;
+                        f_V[k][0] = d.x, f_V[k][1] = d.y, f_V[k][2] = d.z;
+                    }
+                    if (has_refr) f_dist[k] = h.dist;  // absorption on the way out
                     f_prim[k] = h.prim;
                     uint32_t st = h.front ? ST_FRONT : 0;
                     d3 nd;
