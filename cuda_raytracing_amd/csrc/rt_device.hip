@@ -186,7 +186,9 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
                     else k0 = true;
                 }
                 ctr.u[6] += k0, ctr.u[8] += k1, ctr.u[10] += k2;
+#ifndef RT_PAIR_STATS
                 ctr.u[7] += (k0 && !k1 && !k2), ctr.u[9] += (k1 && !k0 && !k2), ctr.u[11] += (k2 && !k0 && !k1);
+#endif
             }
 #endif
             RT_LAP(ctr, PF_CHUNK_SHFL);
@@ -217,6 +219,9 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             }
         }
         RT_LAP(ctr, PF_CHUNK_SHFL);
+#ifdef RT_PAIR_STATS
+        if (heavy) { ctr.u[7] += 1; ctr.u[9] += (cnt == n_l) ? 1u : 0u; ctr.u[11] += (cnt == 0) ? 1u : 0u; }
+#endif
         if (need && dt > RT_EPS) {
             double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
             if (!(shade < RT_EPS)) {
@@ -257,8 +262,8 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
     const int bx0 = tile.x0 + (blk_in_tile % nbx) * 8, by0 = tile.y0 + (blk_in_tile / nbx) * 8;
     // frame k = the hit at depth k+1 that is waiting for a child ray to return
     double f_acc[RT_MAX_DEPTH][3], f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3], f_dist[RT_MAX_DEPTH];
-    int32_t f_prim[RT_MAX_DEPTH];
-    uint32_t f_stage[RT_MAX_DEPTH];
+    uint32_t f_prim[RT_MAX_DEPTH];  // primitive index | stage bits << 28
+    uint32_t top = 0;  // f_prim[sp - 1], kept in a register: the material lookup of a pop need not wait for the stack read
     int sp = 0, my_path = 0, next = 0;
     bool tracing = false;
     uint32_t pixel = 0, smp = 0, draw = 0, no_log = 0;
@@ -362,7 +367,6 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                         f_V[k][0] = d.x, f_V[k][1] = d.y, f_V[k][2] = d.z;
                     }
                     if (has_refr) f_dist[k] = h.dist;  // absorption on the way out
-                    f_prim[k] = h.prim;
                     uint32_t st = h.front ? ST_FRONT : 0;
                     d3 nd;
                     if (has_refl) {  // CalnReflection, CR/Scene_Material.cu:68-99
@@ -391,7 +395,8 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                         if (h.front) n = 1.0 / n;
                         nd = refract(d, h.N, n);
                     }
-                    f_stage[k] = st;
+                    top = (uint32_t)h.prim | st << 28;
+                    f_prim[k] = top;
                     sp++;
                     o = h.C;
                     d = nd;
@@ -400,6 +405,7 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                     have_result = true;
                 }
             }
+            RT_LAP(ctr, PF_SPAWN);
             // hand `result` to the frames that wait for it
             while (have_result) {
                 if (sp == 0) {  // the path is complete
@@ -409,8 +415,8 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                     break;
                 }
                 const int k = sp - 1;
-                const DevShade& m = shade[f_prim[k]];
-                const uint32_t st = f_stage[k];
+                const uint32_t fp = top, st = fp >> 28;
+                const DevShade& m = shade[fp & 0x0fffffffu];
                 d3 contrib;
                 if (st & ST_REFL) {
                     contrib = mulv(result, D3(m.color)) * m.refl;
@@ -424,7 +430,8 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                 d3 acc = D3(f_acc[k][0], f_acc[k][1], f_acc[k][2]) + contrib;
                 if ((st & ST_REFL) && (st & ST_PENDING_REFR)) {
                     f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
-                    f_stage[k] = (st & ST_FRONT) | ST_REFR;
+                    top = (fp & 0x0fffffffu) | ((st & ST_FRONT) | ST_REFR) << 28;
+                    f_prim[k] = top;
                     double n = m.rindex;
                     if (st & ST_FRONT) n = 1.0 / n;
                     d3 V = D3(f_V[k][0], f_V[k][1], f_V[k][2]), N = D3(f_N[k][0], f_N[k][1], f_N[k][2]);
@@ -434,6 +441,7 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                 } else {
                     result = clamp1(acc);
                     sp--;
+                    if (sp > 0) top = f_prim[sp - 1];
                 }
             }
         }
@@ -1294,6 +1302,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     *out = nullptr;
     int rc = validate_desc(d);
     if (rc) return rc;
+    if (d->n_primitives >= (1 << 28)) return rt_fail(RT_ERR_LIMIT, "2^28 primitives or more (the path state keeps the index in 28 bits)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return rt_fail(RT_ERR_NOGPU, "no HIP device visible");
     rt_scene* s = new rt_scene;
@@ -1509,9 +1518,9 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
                  100.0 * c[CTR_U_TRACE_ACTIVE] / (double)(c[CTR_U_TRACE_SLOTS] ? c[CTR_U_TRACE_SLOTS] : 1), c[CTR_U_TRACE_ACTIVE], c[CTR_U_TRACE_SLOTS]);
     static const char* const probe_name[6] = {"shadow mesh walks", "closest mesh walks", "shadow interior steps", "shadow leaf steps",
                                               "closest interior steps", "closest leaf steps"};
-    static const char* const sect[PF_COUNT] = {"task setup / resolve", "frame stack", "closest: analytic prims", "closest: mesh walk", "shade setup + texture",
+    static const char* const sect[PF_COUNT] = {"task setup / resolve", "frame pop / hand-back", "closest: analytic prims", "closest: mesh walk", "shade setup + texture",
                                                "light candidates", "chunk shuffles + counts", "rng + light sample", "shadow: analytic prims", "shadow: mesh walk",
-                                               "shade math"};
+                                               "shade math", "child ray set-up"};
     unsigned long long tot = 0;
     for (int k = 0; k < PF_COUNT; k++) tot += c[CTR_ALL + k];
     for (int k = 0; k < PF_COUNT; k++)

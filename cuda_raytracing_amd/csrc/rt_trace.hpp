@@ -59,7 +59,9 @@ struct DevNode4 {    // 128 bytes
 #ifndef RT_CGRID
 #define RT_CGRID 64
 #endif
+#ifndef RT_SHADE_LDS
 #define RT_SHADE_LDS 64
+#endif
 struct DevShade {  // 216 bytes
     double color[3], absor[3], diff, spec, refl, refr, rindex, drefl;
     double tf[12];  // sphere: O, De, Dc, Dc x De | plane: Dx, Dy, Dx.Dx, Dy.Dy | square: O, Dx, Dy, Dx.Dx, Dy.Dy
@@ -121,7 +123,7 @@ struct Counters {  // per-lane work counters, flushed once per wave
 };
 // sections of the per-wave time profile (util builds)
 enum { PF_TASK = 0, PF_FRAME, PF_CLOSEST_PRIMS, PF_CLOSEST_MESH, PF_SHADE_SETUP, PF_CAND, PF_CHUNK_SHFL, PF_RNG, PF_SH_PRIMS, PF_SH_MESH,
-       PF_SHADE_MATH, PF_COUNT };
+       PF_SHADE_MATH, PF_SPAWN, PF_COUNT };
 // lane-utilisation probe: counts this lane, and 64 slots once per wave-level execution
 #ifdef RT_UTIL_COUNTERS
 #define RT_PROBE(ctr, k)                                                                            \
@@ -992,11 +994,15 @@ DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevShade& px, doub
     if (U2 < 0 || U2 >= H) U2 = 0;
     if (V1 < 0 || V1 >= W) V1 = 0;
     if (V2 < 0 || V2 >= W) V2 = 0;
+    // one 4-byte read per tap (its three channels and one byte of the neighbour; the slab is padded past the last texel)
     const uint8_t* base = sc.texels + px.tex_off;
-    const uint8_t* t11 = base + ((size_t)U1 * W + V1) * 3;
-    const uint8_t* t12 = base + ((size_t)U1 * W + V2) * 3;
-    const uint8_t* t21 = base + ((size_t)U2 * W + V1) * 3;
-    const uint8_t* t22 = base + ((size_t)U2 * W + V2) * 3;
+    uint32_t q11, q12, q21, q22;
+    __builtin_memcpy(&q11, base + ((size_t)U1 * W + V1) * 3, 4);
+    __builtin_memcpy(&q12, base + ((size_t)U1 * W + V2) * 3, 4);
+    __builtin_memcpy(&q21, base + ((size_t)U2 * W + V1) * 3, 4);
+    __builtin_memcpy(&q22, base + ((size_t)U2 * W + V2) * 3, 4);
+    const uint32_t t11[3] = {q11 & 255u, (q11 >> 8) & 255u, (q11 >> 16) & 255u}, t12[3] = {q12 & 255u, (q12 >> 8) & 255u, (q12 >> 16) & 255u};
+    const uint32_t t21[3] = {q21 & 255u, (q21 >> 8) & 255u, (q21 >> 16) & 255u}, t22[3] = {q22 & 255u, (q22 >> 8) & 255u, (q22 >> 16) & 255u};
     double w1a = ru, w1b = rv, w2a = ru, w2b = 1 - rv, w3a = 1 - ru, w3b = rv, w4a = 1 - ru, w4b = 1 - rv;
     double out[3];
 #pragma unroll
