@@ -453,16 +453,17 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 3  // register budget: 512 / RT_WAVES_PER_SIMD VGPRs per lane; measured best (2: 100 ms, 3: 96 ms, 4: 113 ms per frame)
 #endif
-template <bool STRICT>
+// SHADE_LDS: the shading table (at most RT_SHADE_LDS primitives) is copied to LDS and read from there.  A template
+// parameter rather than a run-time choice so that the reads compile to LDS instructions, not to flat ones.
+template <bool STRICT, bool SHADE_LDS>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
     const int lane = lane_id();
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
     __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
     uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
-    // the shading table moves to LDS when it fits: every hit reads a few of its fields, one after another
-    __shared__ DevShade s_shade[RT_SHADE_LDS];
+    __shared__ DevShade s_shade[SHADE_LDS ? RT_SHADE_LDS : 1];
     const DevShade* shade = P.sc.shade;
-    if (P.sc.n_prims <= RT_SHADE_LDS) {
+    if (SHADE_LDS) {  // every hit reads a few fields of its record, one after another
         const int words = P.sc.n_prims * (int)(sizeof(DevShade) / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.sc.shade);
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_shade);
@@ -1504,8 +1505,9 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     P.path_buf = s->path_buf;
     HIPCHK(hipEventRecord(s->ev0, g_stream));
     if (tasks > 0) {
-        if (strict) hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)grid), dim3(256), 0, g_stream, P);
-        else hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        if (strict) hipLaunchKernelGGL((render_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((render_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        else hipLaunchKernelGGL((render_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s->ev1, g_stream));
