@@ -784,7 +784,10 @@ static size_t sah_split(std::vector<SahTri>& tris, size_t b, size_t e, bool bala
         return b + n / 2;
     };
     if (balanced || n <= 2 || !(chi[wide] - clo[wide] > 0)) return median();
-    constexpr int NB = 16;
+#ifndef RT_SAH_BINS
+#define RT_SAH_BINS 16
+#endif
+    constexpr int NB = RT_SAH_BINS;
     double best = 1e300;
     int best_axis = -1, best_bin = 0;
     for (int k = 0; k < 3; k++) {

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Predict the multi-GPU frame time on one GPU: render every rank's share of the headline frame in turn and
+report the slowest share per world size (the ranks run concurrently on a real node, so max = frame time
+without the gather)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cuda_raytracing_amd import abi
+from cuda_raytracing_amd.device import DeviceScene
+from cuda_raytracing_amd.host import SCENE_DIR, HostScene
+
+W, H = 1920, 1080
+hs = HostScene(os.path.join(SCENE_DIR, "c4_lucy.txt"))
+st = abi.Settings(dof_enabled=1, spp=32, focal_distance=1.35, aperture=1.0, seed=1, flags=abi.RT_MODE_GPU_REF)
+ds = DeviceScene(hs, device=0)
+ds.set_stream(torch.cuda.current_stream().cuda_stream)
+image = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+ds.render_frame(st, W, H, tile=32, part=0, n_parts=1, out=image)
+for n in (1, 2, 4, 8):
+    ks, ws = [], []
+    for r in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, s = ds.render_frame(st, W, H, tile=32, part=r, n_parts=n, out=image)
+        torch.cuda.synchronize()
+        ws.append((time.perf_counter() - t0) * 1e3)
+        ks.append(s.kernel_ms)
+    print(f"world {n}: kernel ms per rank min {min(ks):.2f} max {max(ks):.2f} sum {sum(ks):.2f}; wall per call max {max(ws):.2f}; "
+          f"predicted efficiency {ks and (sum(ks) / n) / max(ws) * 100:.0f}% of ideal split", flush=True)
