@@ -41,31 +41,35 @@ struct Tile {
 };
 
 // Work decomposition.  Pixels of a tile are numbered in 8x8 blocks ("slots" 0..63 inside a block, row-major);
-// blocks are numbered tile after tile.  A task is a run of slots inside one block; the first blocks are cut
-// into long tasks, the last ones into shorter and shorter ones so that the waves run dry together:
-//   blocks [0, bA)   : 64 / sA tasks of sA slots each
-//   blocks [bA, bB)  : 64 / sB tasks of sB slots
-//   blocks [bB, nb)  : 64 / sC tasks of sC slots          (sA >= sB >= sC, powers of two)
+// blocks are numbered tile after tile.  Path g of a launch is sample g % spp of slot (g / spp) % 64 of block
+// g / (64 * spp): consecutive paths are consecutive samples of one pixel, then the next pixel of the block.
+// Every wave keeps 64 paths in flight, one per lane, and draws the next unstarted paths from one counter
+// for the whole launch, so all waves stay full until the launch runs dry.  The colour of a finished path goes
+// to path_out[((block * spp + sample) * 64 + slot) * 3]; resolve_kernel adds the samples of a pixel afterwards.
+struct BlockRec {  // one 8x8 block: its pixel origin, and how much of it lies inside its tile
+    uint16_t x0, y0;
+    uint8_t w, h;  // 1..8
+    uint16_t pad_;
+};
+static_assert(sizeof(BlockRec) == 8, "block record");
 struct RenderParams {
     DevScene sc;
     int32_t tex_w, tex_h, spp, dof;
     double focal, aperture;
+    double inv_block_paths, inv_spp;  // reciprocals (rounded up a little) for the path index decode
     uint32_t k0, k1, flags;
-    int32_t n_tiles;
-    uint32_t n_tasks, bA, bB, tA, tB;
-    int32_t sA, sB, sC;
-    const Tile* tiles;
-    const uint32_t* tile_prefix;  // n_tiles + 1 entries: first block of each tile
-    uint32_t* queue;
+    uint32_t n_blocks, n_paths;  // of this launch: n_paths = n_blocks * 64 * spp < 2^30
+    const BlockRec* blocks;
+    uint32_t* queue;   // next unstarted path
     uint8_t* out;      // tex_w * tex_h * 4, row 0 = bottom
-    double* path_buf;  // RT_BATCH_PATHS * 3 doubles per wave of the grid: colours of finished paths
+    double* path_out;  // n_paths * 3 doubles: colours of finished paths
     unsigned long long* counters;
 };
-#ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 24  // idle lanes that trigger a refill (measured: 1: 94 ms, 16: 91, 24-32: 91 at 256 paths per round)
+#ifndef RT_LAUNCH_PATHS
+#define RT_LAUNCH_PATHS (1ull << 28)  // most paths of one launch (their colours take 24 bytes each: 6.4 GB); larger calls are cut into several launches
 #endif
-#ifndef RT_BATCH_PATHS
-#define RT_BATCH_PATHS 1024  // paths of one task round: in flight (one per lane) or waiting for a lane (256: 91 ms, 512: 87, 1024: 84, 2048: 90)
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 24  // idle lanes that trigger a refill: the set-up of new paths is long, and running it for one lane costs the same
 #endif
 
 enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT,
@@ -248,43 +252,52 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
 // ---- one path per lane: CR/Scene.cu:23-58 + CR/Scene_Material.cu:68-118 as a loop ----------------
 enum { ST_REFL = 1, ST_REFR = 2, ST_PENDING_REFR = 4, ST_FRONT = 8 };
 
-// One round of a task: `n_slots` pixel slots x samples [s_begin, s_end).  Path p of the round is
-// sample s_begin + p % ns of slot slot0 + p / ns.  The wave keeps up to 64 paths in flight, one per
-// lane; a lane whose path has ended takes the next unstarted one, so the lanes stay busy until the
-// round runs out ("path regeneration").  Finished colours go to buf[p].
+// q = n / d for n < 2^31, with inv a double slightly above 1 / d: the estimate is exact or one too large
+DEV uint32_t div_by(uint32_t n, uint32_t d, double inv) {
+    uint32_t q = (uint32_t)((double)n * inv);
+    if (q * d > n) q--;
+    return q;
+}
+
+// All paths of a launch.  The wave keeps up to 64 paths in flight, one per lane; lanes whose path has ended wait
+// until enough of them are idle, then take the next unstarted paths of the launch together ("path regeneration").
 template <bool STRICT>
-DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile tile, int blk_in_tile, int slot0, int n_slots, int s_begin,
-                     int s_end, double* buf, Counters& ctr, uint32_t* stk) {
+DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ctr, uint32_t* stk) {
     const DevScene& sc = P.sc;
-    const int ns = s_end - s_begin;
-    const int n_paths = n_slots * ns;
-    const int nbx = (tile.w + 7) >> 3;
-    const int bx0 = tile.x0 + (blk_in_tile % nbx) * 8, by0 = tile.y0 + (blk_in_tile / nbx) * 8;
     // frame k = the hit at depth k+1 that is waiting for a child ray to return
     double f_acc[RT_MAX_DEPTH][3], f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3], f_dist[RT_MAX_DEPTH];
     uint32_t f_prim[RT_MAX_DEPTH];  // primitive index | stage bits << 28
     uint32_t top = 0;  // f_prim[sp - 1], kept in a register: the material lookup of a pop need not wait for the stack read
-    int sp = 0, my_path = 0, next = 0;
-    bool tracing = false;
+    int sp = 0;
+    uint32_t my_path = 0;  // where this lane's colour goes in path_out
+    bool tracing = false, drained = false;
     uint32_t pixel = 0, smp = 0, draw = 0, no_log = 0;
     d3 o = D3(0, 0, 0), d = D3(0, 0, 1);
+    const uint32_t block_paths = 64u * (uint32_t)P.spp;
 
     for (;;) {
-        // ---- idle lanes start the next paths of the round (CR/RayTracer.cu:52-72) ----
-        // (only when enough lanes wait: the set-up below is long, and running it for one lane costs the same)
+        // ---- idle lanes start the next paths of the launch (CR/RayTracer.cu:52-72) ----
         const unsigned long long idle = __ballot(!tracing);
-        if (next < n_paths && (__popcll(idle) >= RT_REFILL_MIN || idle == ~0ull)) {
-            const int p = next + rank_in(idle);
-            if (!tracing && p < n_paths) {
-                const int q = p / ns, s = s_begin + (p - q * ns), inb = slot0 + q;
-                const int px = bx0 + (inb & 7), py = by0 + (inb >> 3);
-                if (px < tile.x0 + tile.w && py < tile.y0 + tile.h) {
+        if (!drained && (__popcll(idle) >= RT_REFILL_MIN || idle == ~0ull)) {
+            const uint32_t n_new = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane_id() == 0) base = atomicAdd(P.queue, n_new);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + n_new >= P.n_paths) drained = true;
+            const uint32_t g = base + (uint32_t)rank_in(idle);
+            if (!tracing && g < P.n_paths) {
+                const uint32_t blk = div_by(g, block_paths, P.inv_block_paths), r = g - blk * block_paths;
+                const uint32_t slot = div_by(r, (uint32_t)P.spp, P.inv_spp), s = r - slot * (uint32_t)P.spp;
+                const BlockRec rec = P.blocks[blk];
+                if ((slot & 7u) < rec.w && (slot >> 3) < rec.h) {
+                    const int px = rec.x0 + (int)(slot & 7u), py = rec.y0 + (int)(slot >> 3);
                     int x, y;
                     map_pixel(P, px, py, x, y);
                     const d3 dc = unit(emit(sc, x, y));
                     pixel = (uint32_t)py * (uint32_t)P.tex_w + (uint32_t)px;
-                    smp = (uint32_t)s;
-                    my_path = p, sp = 0, draw = 0, tracing = true;
+                    smp = s;
+                    my_path = (blk * (uint32_t)P.spp + s) * 64u + slot;
+                    sp = 0, draw = 0, tracing = true;
                     o = sc.camO, d = dc;
                     if (P.spp == 1) {
                         if (!(P.flags & RT_F_NORMALIZE_PRIMARY)) d = emit(sc, x, y);
@@ -309,11 +322,10 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
                     }
                 }
             }
-            next += __popcll(idle);
         }
         if (__ballot(tracing) == 0ull) {
-            if (next >= n_paths) break;
-            continue;  // every slot just handed out lies outside the tile
+            if (drained) break;
+            continue;  // every slot just handed out lies outside its tile
         }
         RT_LAP(ctr, PF_TASK);
 
@@ -409,7 +421,7 @@ DEV void trace_batch(const RenderParams& P, const DevShade* shade, const Tile ti
             // hand `result` to the frames that wait for it
             while (have_result) {
                 if (sp == 0) {  // the path is complete
-                    double* dst = buf + (size_t)my_path * 3;
+                    double* dst = P.path_out + (size_t)my_path * 3;
                     dst[0] = result.x, dst[1] = result.y, dst[2] = result.z;
                     tracing = false;
                     break;
@@ -480,64 +492,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     ctr.prof = s_prof[threadIdx.x >> 6];
     if (lane < 1 + PF_COUNT) ctr.prof[lane] = lane == 0 ? __builtin_readcyclecounter() : 0ull;
 #endif
-    const int spp = P.spp;
-    double* buf = P.path_buf + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (size_t)(RT_BATCH_PATHS * 3);
-
-    for (;;) {
-        uint32_t task = 0;
-        if (lane == 0) task = atomicAdd(P.queue, 1u);
-        task = (uint32_t)__builtin_amdgcn_readfirstlane((int)task);
-        if (task >= P.n_tasks) break;
-        // task -> (block, first slot, slots)
-        uint32_t blk;
-        int S, per, sub;
-        if (task < P.tA) {
-            S = P.sA, per = 64 / S, blk = task / (uint32_t)per, sub = (int)(task % (uint32_t)per);
-        } else if (task < P.tB) {
-            const uint32_t u = task - P.tA;
-            S = P.sB, per = 64 / S, blk = P.bA + u / (uint32_t)per, sub = (int)(u % (uint32_t)per);
-        } else {
-            const uint32_t u = task - P.tB;
-            S = P.sC, per = 64 / S, blk = P.bB + u / (uint32_t)per, sub = (int)(u % (uint32_t)per);
-        }
-        int lo = 0, hi = P.n_tiles;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (P.tile_prefix[mid] <= blk) lo = mid;
-            else hi = mid;
-        }
-        const Tile tile = P.tiles[lo];
-        const int blk_in_tile = (int)(blk - P.tile_prefix[lo]);
-        const int slot0 = sub * S;
-        const int nbx = (tile.w + 7) >> 3;
-        // samples per round: everything at once if the colours fit the wave's buffer, else one slot in rounds
-        const int round = (S * spp <= RT_BATCH_PATHS) ? spp : RT_BATCH_PATHS;
-        d3 acc = D3(0, 0, 0);
-        for (int s0 = 0; s0 < spp; s0 += round) {
-            const int s1 = s0 + round < spp ? s0 + round : spp;
-            trace_batch<STRICT>(P, shade, tile, blk_in_tile, slot0, S, s0, s1, buf, ctr, stk);
-            // Pixel sums: lane j adds the samples of slot j in sample order (the reference adds them in that order
-            // inside one thread, CR/RayTracer.cu:74-84).  The colours were written by other lanes of this wave; a
-            // fence of work-group scope orders them before the reads without flushing the CU's vector cache, which
-            // the other waves are walking the BVH through.
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            const int ns = s1 - s0;
-            for (int j = lane; j < S; j += 64) {  // S <= 64: one pass
-                const double* src = buf + (size_t)j * ns * 3;
-                for (int k = 0; k < ns; k++) acc = acc + D3(src[3 * k], src[3 * k + 1], src[3 * k + 2]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next round overwrites the buffer
-        }
-        if (lane < S) {
-            const int inb = slot0 + lane;
-            const int px = tile.x0 + (blk_in_tile % nbx) * 8 + (inb & 7), py = tile.y0 + (blk_in_tile / nbx) * 8 + (inb >> 3);
-            if (px < tile.x0 + tile.w && py < tile.y0 + tile.h) {
-                if (spp > 1) acc = acc / (double)spp;
-                uint32_t rgba = to_u8(acc.x) | (to_u8(acc.y) << 8) | (to_u8(acc.z) << 16) | 0xFF000000u;
-                *reinterpret_cast<uint32_t*>(P.out + ((size_t)py * (size_t)P.tex_w + (size_t)px) * 4) = rgba;
-            }
-        }
-    }
+    trace_stream<STRICT>(P, shade, ctr, stk);
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_TASK);
     if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);
@@ -554,6 +509,24 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
         unsigned long long s = wave_sum_u64(v[i]);
         if (lane == 0 && s) atomicAdd(&P.counters[i], s);
     }
+}
+
+// ---- pixel sums: CR/RayTracer.cu:74-89 ---------------------------------------------------------
+// One wave per 8x8 block, lane = slot.  The samples of a pixel are added in sample order, because the reference
+// adds them in that order inside one thread and double addition is not associative.
+__global__ __launch_bounds__(256) void resolve_kernel(RenderParams P) {
+    const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t slot = threadIdx.x & 63u;
+    if (blk >= P.n_blocks) return;
+    const BlockRec rec = P.blocks[blk];
+    if ((slot & 7u) >= rec.w || (slot >> 3) >= rec.h) return;
+    const double* src = P.path_out + ((size_t)blk * (size_t)P.spp * 64u + slot) * 3;
+    d3 acc = D3(0, 0, 0);
+    for (int k = 0; k < P.spp; k++, src += 64 * 3) acc = acc + D3(src[0], src[1], src[2]);
+    if (P.spp > 1) acc = acc / (double)P.spp;
+    const int px = rec.x0 + (int)(slot & 7u), py = rec.y0 + (int)(slot >> 3);
+    const uint32_t rgba = to_u8(acc.x) | (to_u8(acc.y) << 8) | (to_u8(acc.z) << 16) | 0xFF000000u;
+    *reinterpret_cast<uint32_t*>(P.out + ((size_t)py * (size_t)P.tex_w + (size_t)px) * 4) = rgba;
 }
 
 // ---- debug kernel: primary ray of every pixel, reference-order walk with a visit log ------------
@@ -607,11 +580,10 @@ struct rt_scene {
     unsigned long long* counters = nullptr;  // CTR_COUNT work counters
     uint8_t* image = nullptr;              // staging image for host destinations
     size_t image_bytes = 0;
-    double* path_buf = nullptr;            // colours of finished paths, RT_BATCH_PATHS per wave of the grid
-    size_t path_buf_bytes = 0;
-    Tile* tiles = nullptr;                 // tile list + prefix of the current call
-    uint32_t* prefix = nullptr;
-    size_t tiles_cap = 0;
+    double* path_out = nullptr;            // colours of the finished paths of one launch
+    size_t path_out_bytes = 0;
+    BlockRec* blocks = nullptr;            // 8x8 blocks of the current call
+    size_t blocks_cap = 0;
     int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int desc_cam_w = 0, desc_cam_h = 0;
@@ -1293,9 +1265,8 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (s->queue) (void)hipFree(s->queue);
     if (s->counters) (void)hipFree(s->counters);
     if (s->image) (void)hipFree(s->image);
-    if (s->path_buf) (void)hipFree(s->path_buf);
-    if (s->tiles) (void)hipFree(s->tiles);
-    if (s->prefix) (void)hipFree(s->prefix);
+    if (s->path_out) (void)hipFree(s->path_out);
+    if (s->blocks) (void)hipFree(s->blocks);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -1437,49 +1408,41 @@ static int check_common(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
 // Render the given tiles into `dst` (device image).  Fills kernel time and counters.
 static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, const std::vector<Tile>& tiles,
                         uint8_t* dst, rt_stats* stats) {
-    std::vector<uint32_t> prefix(tiles.size() + 1, 0);
-    uint64_t pixels = 0, blocks = 0;
-    for (size_t i = 0; i < tiles.size(); i++) {
-        const Tile& t = tiles[i];
-        prefix[i] = (uint32_t)blocks;
-        blocks += (uint64_t)((t.w + 7) / 8) * ((t.h + 7) / 8);
+    // the 8x8 blocks of the tiles, tile after tile
+    std::vector<BlockRec> recs;
+    uint64_t pixels = 0;
+    for (const Tile& t : tiles) {
         pixels += (uint64_t)t.w * t.h;
-        if (blocks >= (1ull << 24)) return rt_fail(RT_ERR_LIMIT, "too many pixels in one call");
+        for (int by = 0; by < t.h; by += 8)
+            for (int bx = 0; bx < t.w; bx += 8) {
+                BlockRec r;
+                r.x0 = (uint16_t)(t.x0 + bx), r.y0 = (uint16_t)(t.y0 + by);
+                r.w = (uint8_t)std::min(8, t.w - bx), r.h = (uint8_t)std::min(8, t.h - by), r.pad_ = 0;
+                recs.push_back(r);
+            }
+        if (recs.size() >= (1ull << 24)) return rt_fail(RT_ERR_LIMIT, "too many pixels in one call");
     }
-    prefix[tiles.size()] = (uint32_t)blocks;
+    const uint64_t blocks = recs.size();
     const bool strict = (st->flags & RT_F_STRICT_TRAVERSAL) != 0;
     const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
-    const uint64_t waves = (uint64_t)s->cus * bpc * 4;
-    // Slots per task: as many as the wave's colour buffer holds (long tasks keep the lanes refilled), fewer
-    // if the image is too small to give every wave several tasks, never fewer than one wave's worth of paths.
-    int s_max = 64;
-    while (s_max > 1 && (uint64_t)s_max * st->spp > RT_BATCH_PATHS) s_max >>= 1;
-    int s_min = 1;
-    while (s_min < 64 && s_min * st->spp < 64) s_min <<= 1;
-    if (s_min > s_max) s_min = s_max;
-    int sA = s_max;
-    while (sA > s_min && blocks * (uint64_t)(64 / sA) < 4 * waves) sA >>= 1;
-    const int sB = std::max(s_min, sA / 4), sC = std::max(s_min, sA / 16);
-#ifndef RT_PHASE_A
-#define RT_PHASE_A 80
-#define RT_PHASE_B 95
-#endif
-    const uint32_t bA = (uint32_t)(blocks * RT_PHASE_A / 100), bB = (uint32_t)(blocks * RT_PHASE_B / 100);
-    const uint64_t tA = (uint64_t)bA * (64 / sA), tB = tA + (uint64_t)(bB - bA) * (64 / sB);
-    const uint64_t tasks = tB + (blocks - bB) * (uint64_t)(64 / sC);
-    if (tasks >= (1ull << 31)) return rt_fail(RT_ERR_LIMIT, "too many tasks in one call");
-    if (tiles.size() > s->tiles_cap) {
-        if (s->tiles) (void)hipFree(s->tiles);
-        if (s->prefix) (void)hipFree(s->prefix);
-        s->tiles = nullptr, s->prefix = nullptr, s->tiles_cap = 0;
-        size_t cap = tiles.size() + 64;
-        HIPCHK(hipMalloc(&s->tiles, cap * sizeof(Tile)));
-        HIPCHK(hipMalloc(&s->prefix, (cap + 1) * sizeof(uint32_t)));
-        s->tiles_cap = cap;
+    // blocks per launch: the colours of all paths of a launch are kept until its pixel sums are taken
+    const uint64_t block_paths = 64ull * (uint64_t)st->spp;
+    const uint64_t chunk_blocks = std::max<uint64_t>(1, RT_LAUNCH_PATHS / block_paths);
+    if (blocks > s->blocks_cap) {
+        if (s->blocks) (void)hipFree(s->blocks);
+        s->blocks = nullptr, s->blocks_cap = 0;
+        const size_t cap = blocks + 1024;
+        HIPCHK(hipMalloc(&s->blocks, cap * sizeof(BlockRec)));
+        s->blocks_cap = cap;
     }
-    HIPCHK(hipMemcpyAsync(s->tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, g_stream));
-    HIPCHK(hipMemcpyAsync(s->prefix, prefix.data(), prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, g_stream));
-    HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
+    const size_t out_bytes = (size_t)(std::min(blocks, chunk_blocks) * block_paths) * 3 * sizeof(double);
+    if (s->path_out_bytes < out_bytes) {
+        if (s->path_out) (void)hipFree(s->path_out);
+        s->path_out = nullptr, s->path_out_bytes = 0;
+        HIPCHK(hipMalloc(&s->path_out, out_bytes));
+        s->path_out_bytes = out_bytes;
+    }
+    if (blocks) HIPCHK(hipMemcpyAsync(s->blocks, recs.data(), blocks * sizeof(BlockRec), hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));
 
     RenderParams P;
@@ -1488,29 +1451,24 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     P.sc.cam_h = cam_h > 0 ? cam_h : s->desc_cam_h;
     P.tex_w = tex_w, P.tex_h = tex_h, P.spp = st->spp, P.dof = st->dof_enabled ? 1 : 0;
     P.focal = st->focal_distance, P.aperture = st->aperture;
+    P.inv_block_paths = 1.0 / (double)block_paths * (1.0 + 1e-12), P.inv_spp = 1.0 / (double)st->spp * (1.0 + 1e-12);
     P.k0 = (uint32_t)st->seed, P.k1 = (uint32_t)(st->seed >> 32), P.flags = st->flags;
-    P.n_tiles = (int)tiles.size(), P.n_tasks = (uint32_t)tasks;
-    P.bA = bA, P.bB = bB, P.tA = (uint32_t)tA, P.tB = (uint32_t)tB, P.sA = sA, P.sB = sB, P.sC = sC;
-    P.tiles = s->tiles, P.tile_prefix = s->prefix, P.queue = s->queue, P.out = dst, P.counters = s->counters;
+    P.queue = s->queue, P.out = dst, P.counters = s->counters, P.path_out = s->path_out;
 
-    uint64_t want_blocks = (tasks + 3) / 4;
-    uint64_t grid = (uint64_t)s->cus * bpc;
-    if (grid > want_blocks) grid = want_blocks;
-    if (grid < 1) grid = 1;
-    // colours of finished paths, one buffer per wave of the grid
-    const size_t buf_bytes = (size_t)grid * 4 * RT_BATCH_PATHS * 3 * sizeof(double);
-    if (s->path_buf_bytes < buf_bytes) {
-        if (s->path_buf) (void)hipFree(s->path_buf);
-        s->path_buf = nullptr, s->path_buf_bytes = 0;
-        HIPCHK(hipMalloc(&s->path_buf, buf_bytes));
-        s->path_buf_bytes = buf_bytes;
-    }
-    P.path_buf = s->path_buf;
     HIPCHK(hipEventRecord(s->ev0, g_stream));
-    if (tasks > 0) {
+    for (uint64_t b0 = 0; b0 < blocks; b0 += chunk_blocks) {
+        const uint64_t nb = std::min(chunk_blocks, blocks - b0);
+        P.blocks = s->blocks + b0, P.n_blocks = (uint32_t)nb, P.n_paths = (uint32_t)(nb * block_paths);
+        HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
+        // persistent grid: every wave draws paths until the launch runs dry
+        uint64_t grid = (uint64_t)s->cus * bpc;
+        const uint64_t want_blocks = ((uint64_t)P.n_paths + 255) / 256;
+        if (grid > want_blocks) grid = want_blocks;
         if (strict) hipLaunchKernelGGL((render_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
         else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((render_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
         else hipLaunchKernelGGL((render_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, g_stream, P);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(s->ev1, g_stream));
