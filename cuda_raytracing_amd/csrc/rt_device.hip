@@ -59,8 +59,9 @@ struct RenderParams {
     double inv_block_paths, inv_spp;  // reciprocals (rounded up a little) for the path index decode
     uint32_t k0, k1, flags;
     uint32_t n_blocks, n_paths;  // of this launch: n_paths = n_blocks * 64 * spp < 2^30
+    uint32_t range_paths;        // paths per range (a whole number of blocks); eight ranges cover the launch
     const BlockRec* blocks;
-    uint32_t* queue;   // next unstarted path
+    uint32_t* queue;   // eight words: paths handed out of each range
     uint8_t* out;      // tex_w * tex_h * 4, row 0 = bottom
     double* path_out;  // n_paths * 3 doubles: colours of finished paths
     unsigned long long* counters;
@@ -272,6 +273,9 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
     int sp = 0;
     uint32_t my_path = 0;  // where this lane's colour goes in path_out
     bool tracing = false, drained = false;
+    // The paths of a launch form eight contiguous ranges, each with a queue head of its own.  Waves of blocks b, b + 8, ...
+    // tend to share an XCD and its L2: they start on one range, so that one L2 sees one part of the image.
+    uint32_t range = blockIdx.x & 7u, ranges_done = 0;
     uint32_t pixel = 0, smp = 0, draw = 0, no_log = 0;
     d3 o = D3(0, 0, 0), d = D3(0, 0, 1);
     const uint32_t block_paths = 64u * (uint32_t)P.spp;
@@ -281,12 +285,24 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
         const unsigned long long idle = __ballot(!tracing);
         if (!drained && (__popcll(idle) >= RT_REFILL_MIN || idle == ~0ull)) {
             const uint32_t n_new = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane_id() == 0) base = atomicAdd(P.queue, n_new);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base + n_new >= P.n_paths) drained = true;
+            uint32_t base = 0, end = 0;
+            for (;;) {  // this wave's range first; the ranges after it once theirs are used up
+                const uint32_t first = range * P.range_paths;
+                end = first + P.range_paths < P.n_paths ? first + P.range_paths : P.n_paths;
+                if (first < end) {
+                    if (lane_id() == 0) base = atomicAdd(P.queue + range, n_new);
+                    base = first + (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base < end) break;
+                }
+                range = (range + 1u) & 7u;
+                if (++ranges_done == 8) {
+                    drained = true;
+                    base = end = 0;
+                    break;
+                }
+            }
             const uint32_t g = base + (uint32_t)rank_in(idle);
-            if (!tracing && g < P.n_paths) {
+            if (!tracing && g < end) {
                 const uint32_t blk = div_by(g, block_paths, P.inv_block_paths), r = g - blk * block_paths;
                 const uint32_t slot = div_by(r, (uint32_t)P.spp, P.inv_spp), s = r - slot * (uint32_t)P.spp;
                 const BlockRec rec = P.blocks[blk];
@@ -1460,6 +1476,7 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     for (uint64_t b0 = 0; b0 < blocks; b0 += chunk_blocks) {
         const uint64_t nb = std::min(chunk_blocks, blocks - b0);
         P.blocks = s->blocks + b0, P.n_blocks = (uint32_t)nb, P.n_paths = (uint32_t)(nb * block_paths);
+        P.range_paths = (uint32_t)(((nb + 7) / 8) * block_paths);
         HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
         // persistent grid: every wave draws paths until the launch runs dry
         uint64_t grid = (uint64_t)s->cus * bpc;
