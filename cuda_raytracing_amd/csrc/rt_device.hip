@@ -599,8 +599,9 @@ struct rt_scene {
     size_t image_bytes = 0;
     double* path_out = nullptr;            // colours of the finished paths of one launch
     size_t path_out_bytes = 0;
-    BlockRec* blocks = nullptr;            // 8x8 blocks of the current call
-    size_t blocks_cap = 0;
+    BlockRec* blocks = nullptr;            // 8x8 blocks of the tiles of the last call, in queue order
+    size_t blocks_cap = 0, n_blocks = 0;
+    std::vector<Tile> last_tiles;
     int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int desc_cam_w = 0, desc_cam_h = 0;
@@ -1425,33 +1426,51 @@ static int check_common(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
 // Render the given tiles into `dst` (device image).  Fills kernel time and counters.
 static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, const std::vector<Tile>& tiles,
                         uint8_t* dst, rt_stats* stats) {
-    // the 8x8 blocks of the tiles, tile after tile
-    std::vector<BlockRec> recs;
+    // The 8x8 blocks of the tiles in Z-order: blocks that follow each other in the queue are neighbours in the image,
+    // and each of the eight ranges of the queue is a compact region (its rays meet the same part of the scene in L2).
+    // The list is kept from call to call: a renderer asks for the same tiles frame after frame.
     uint64_t pixels = 0;
-    for (const Tile& t : tiles) {
-        pixels += (uint64_t)t.w * t.h;
-        for (int by = 0; by < t.h; by += 8)
-            for (int bx = 0; bx < t.w; bx += 8) {
-                BlockRec r;
-                r.x0 = (uint16_t)(t.x0 + bx), r.y0 = (uint16_t)(t.y0 + by);
-                r.w = (uint8_t)std::min(8, t.w - bx), r.h = (uint8_t)std::min(8, t.h - by), r.pad_ = 0;
-                recs.push_back(r);
-            }
-        if (recs.size() >= (1ull << 24)) return rt_fail(RT_ERR_LIMIT, "too many pixels in one call");
+    for (const Tile& t : tiles) pixels += (uint64_t)t.w * t.h;
+    const bool same_tiles = s->last_tiles.size() == tiles.size() &&
+                            (tiles.empty() || std::memcmp(s->last_tiles.data(), tiles.data(), tiles.size() * sizeof(Tile)) == 0);
+    if (!same_tiles) {
+        auto spread = [](uint32_t v) {
+            v &= 0xFFFFu;
+            v = (v | (v << 8)) & 0x00FF00FFu, v = (v | (v << 4)) & 0x0F0F0F0Fu, v = (v | (v << 2)) & 0x33333333u, v = (v | (v << 1)) & 0x55555555u;
+            return v;
+        };
+        std::vector<std::pair<uint32_t, BlockRec>> keyed;
+        for (const Tile& t : tiles) {
+            for (int by = 0; by < t.h; by += 8)
+                for (int bx = 0; bx < t.w; bx += 8) {
+                    BlockRec r;
+                    r.x0 = (uint16_t)(t.x0 + bx), r.y0 = (uint16_t)(t.y0 + by);
+                    r.w = (uint8_t)std::min(8, t.w - bx), r.h = (uint8_t)std::min(8, t.h - by), r.pad_ = 0;
+                    keyed.push_back({spread((uint32_t)r.x0 >> 3) | (spread((uint32_t)r.y0 >> 3) << 1), r});
+                }
+            if (keyed.size() >= (1ull << 24)) return rt_fail(RT_ERR_LIMIT, "too many pixels in one call");
+        }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        std::vector<BlockRec> recs(keyed.size());
+        for (size_t i = 0; i < keyed.size(); i++) recs[i] = keyed[i].second;
+        if (recs.size() > s->blocks_cap) {
+            if (s->blocks) (void)hipFree(s->blocks);
+            s->blocks = nullptr, s->blocks_cap = 0;
+            const size_t cap = recs.size() + 1024;
+            HIPCHK(hipMalloc(&s->blocks, cap * sizeof(BlockRec)));
+            s->blocks_cap = cap;
+        }
+        s->last_tiles.clear();  // stays empty if the copy fails
+        if (!recs.empty()) HIPCHK(hipMemcpy(s->blocks, recs.data(), recs.size() * sizeof(BlockRec), hipMemcpyHostToDevice));
+        s->last_tiles = tiles;
+        s->n_blocks = recs.size();
     }
-    const uint64_t blocks = recs.size();
+    const uint64_t blocks = s->n_blocks;
     const bool strict = (st->flags & RT_F_STRICT_TRAVERSAL) != 0;
     const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
     // blocks per launch: the colours of all paths of a launch are kept until its pixel sums are taken
     const uint64_t block_paths = 64ull * (uint64_t)st->spp;
     const uint64_t chunk_blocks = std::max<uint64_t>(1, RT_LAUNCH_PATHS / block_paths);
-    if (blocks > s->blocks_cap) {
-        if (s->blocks) (void)hipFree(s->blocks);
-        s->blocks = nullptr, s->blocks_cap = 0;
-        const size_t cap = blocks + 1024;
-        HIPCHK(hipMalloc(&s->blocks, cap * sizeof(BlockRec)));
-        s->blocks_cap = cap;
-    }
     const size_t out_bytes = (size_t)(std::min(blocks, chunk_blocks) * block_paths) * 3 * sizeof(double);
     if (s->path_out_bytes < out_bytes) {
         if (s->path_out) (void)hipFree(s->path_out);
@@ -1459,7 +1478,6 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         HIPCHK(hipMalloc(&s->path_out, out_bytes));
         s->path_out_bytes = out_bytes;
     }
-    if (blocks) HIPCHK(hipMemcpyAsync(s->blocks, recs.data(), blocks * sizeof(BlockRec), hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));
 
     RenderParams P;

@@ -10,7 +10,7 @@ import sys, json
 seen = set()
 for line in sys.stdin:
     if line.startswith('{'):
-        j = json.loads(line); print('ms_per_step', round(j['ms_per_step'], 2))
+        j = json.loads(line); print('ms_per_step', round(j['ms_per_step'], 2), 'kernel_ms', round(j['roofline']['kernel_ms_avg'], 2))
     elif ('[util]' in line or '[time]' in line) and line not in seen:
         seen.add(line); print(line.rstrip())
 " >> gpurun_out/ab.log || exit 1
