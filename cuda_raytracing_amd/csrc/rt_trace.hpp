@@ -690,6 +690,14 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
         double t = RT_BIG_DIST;
         // a hit can only replace the best one if it is closer (or within 1e-6 under later-wins)
         const double lim = later_wins ? best.dist + RT_EPS : best.dist;
+#ifdef RT_ABLATE_CLOSEST_PRIMS  // timing experiments only: 1 = meshes and planes only, 2 = no spheres
+        if (RT_ABLATE_CLOSEST_PRIMS == 1 && g.type != RT_PRIM_MESH && g.type != RT_PRIM_PLANE) continue;
+        if (RT_ABLATE_CLOSEST_PRIMS == 2 && g.type == RT_PRIM_SPHERE) continue;
+        if (RT_ABLATE_CLOSEST_PRIMS == 3 && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER)) continue;
+        if (RT_ABLATE_CLOSEST_PRIMS == 4 && sc.n_prims > 0 && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER)) continue;  // code kept, work skipped
+        if (RT_ABLATE_CLOSEST_PRIMS == 5 && sc.n_prims > 0 && g.type == RT_PRIM_BEZIER) continue;
+        if (RT_ABLATE_CLOSEST_PRIMS == 6 && sc.n_prims > 0 && g.type == RT_PRIM_CYLINDER) continue;
+#endif
         switch (g.type) {
             case RT_PRIM_SPHERE: t = sphere_hit<true>(g, o, V, tmp); break;
             case RT_PRIM_PLANE: t = plane_hit<true>(g, o, V, tmp); break;
