@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1470,7 +1471,12 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
     // blocks per launch: the colours of all paths of a launch are kept until its pixel sums are taken
     const uint64_t block_paths = 64ull * (uint64_t)st->spp;
-    const uint64_t chunk_blocks = std::max<uint64_t>(1, RT_LAUNCH_PATHS / block_paths);
+    uint64_t launch_paths = RT_LAUNCH_PATHS;
+    if (const char* e = std::getenv("RT_AMD_LAUNCH_PATHS")) {  // smaller launches on request (tests of the multi-launch path, small-memory runs)
+        const unsigned long long v = std::strtoull(e, nullptr, 10);
+        if (v >= 64 && v < launch_paths) launch_paths = v;
+    }
+    const uint64_t chunk_blocks = std::max<uint64_t>(1, launch_paths / block_paths);
     const size_t out_bytes = (size_t)(std::min(blocks, chunk_blocks) * block_paths) * 3 * sizeof(double);
     if (s->path_out_bytes < out_bytes) {
         if (s->path_out) (void)hipFree(s->path_out);

@@ -146,7 +146,7 @@ def test_bezier_primary_hits_bit_exact(stacked):
     assert same_double(t, o_t)
 
 
-@pytest.mark.parametrize("spp", [1, 3, 32, 64, 100, 1500])  # 1500: more samples than a wave buffers, summed over two rounds
+@pytest.mark.parametrize("spp", [1, 3, 32, 64, 100, 1500])
 def test_sample_counts(spp):
     """1 lane per sample: groups that do not divide 64 and counts above 64 (several passes)."""
     hs = scene("t_icosa")
@@ -157,6 +157,24 @@ def test_sample_counts(spp):
         img, stats = ds.render_frame(st, W, H)
     assert_colour_close(img, ref, f"spp={spp}")
     assert stats.rays == ostats.rays
+
+
+def test_call_cut_into_several_launches(monkeypatch):
+    """A call with more paths than one launch may hold runs as several launches (here: at most 2 blocks each)."""
+    hs = scene("t_icosa")
+    W, H = 70, 45
+    st = orc.settings(spp=5, dof=True, focal=9.0, aperture=1.0, seed=11, flags=abi.RT_MODE_GPU_REF)
+    with device_scene(hs) as ds:
+        whole, ws = ds.render_frame(st, W, H)
+        monkeypatch.setenv("RT_AMD_LAUNCH_PATHS", str(2 * 64 * 5))
+        cut, cs = ds.render_frame(st, W, H, tile=16)
+        monkeypatch.setenv("RT_AMD_LAUNCH_PATHS", "64")  # less than one block: one block per launch
+        rect = (3, 2, 30, 21)
+        canvas = np.zeros_like(whole)
+        ds.render_tile(st, W, H, rect, out=canvas)
+    assert np.array_equal(cut, whole) and cs.rays == ws.rays
+    x0, y0, w, h = rect
+    assert np.array_equal(canvas[y0:y0 + h, x0:x0 + w], whole[y0:y0 + h, x0:x0 + w])
 
 
 FLAGS = [abi.RT_F_NORMALIZE_PRIMARY, abi.RT_F_SKY_Y, abi.RT_F_TIE_LATER_WINS, abi.RT_F_SHADOW_SELF_SKIP, abi.RT_F_SQUARE_UV_NO_ORIGIN,
