@@ -183,7 +183,7 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             const unsigned long long ocand = STRICT ? ~0ull : __shfl(cand, owner, 64);
             bool clear = false;
 #ifdef RT_UTIL_COUNTERS
-            if (act && !STRICT) {  // which kinds of primitives make this ray necessary
+            if (act && !STRICT && RT_PROBE_KINDS == 3) {  // which kinds of primitives make this ray necessary
                 bool k0 = false, k1 = false, k2 = false;
                 for (int j = 0; j < sc.n_prims && j < 64; j++) {
                     if (!((ocand >> j) & 1ull)) continue;
@@ -1532,7 +1532,7 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         std::fprintf(stderr, "[time] %-26s %5.1f%%\n", sect[k], 100.0 * c[CTR_ALL + k] / (double)(tot ? tot : 1));
     std::fprintf(stderr, "[util] shadow rays traced because of: sphere/plane/square %llu (only: %llu), cylinder/bezier %llu (only: %llu), mesh %llu (only: %llu)\n",
                  c[CTR_U_PROBES + 6], c[CTR_U_PROBES + 7], c[CTR_U_PROBES + 8], c[CTR_U_PROBES + 9], c[CTR_U_PROBES + 10], c[CTR_U_PROBES + 11]);
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < RT_PROBE_KINDS; k++) {
         const unsigned long long lanes = c[CTR_U_PROBES + 2 * k], slots = c[CTR_U_PROBES + 2 * k + 1];
         std::fprintf(stderr, "[util] %-24s lanes %.1f%% (%llu lane executions, %llu wave executions)\n", probe_name[k],
                      100.0 * lanes / (double)(slots ? slots : 1), lanes, slots / 64);
