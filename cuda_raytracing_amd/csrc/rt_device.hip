@@ -483,17 +483,18 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 3  // register budget: 512 / RT_WAVES_PER_SIMD VGPRs per lane; measured best (2: 100 ms, 3: 96 ms, 4: 113 ms per frame)
 #endif
-// SHADE_LDS: the shading table (at most RT_SHADE_LDS primitives) is copied to LDS and read from there.  A template
-// parameter rather than a run-time choice so that the reads compile to LDS instructions, not to flat ones.
-template <bool STRICT, bool SHADE_LDS>
+// SHADE_CAP > 0: the shading table (at most SHADE_CAP primitives) is copied to LDS and read from there.  A template
+// parameter rather than a run-time choice so that the reads compile to LDS instructions, not to flat ones; two
+// capacities because a smaller LDS footprint measures 1 % faster on small scenes.
+template <bool STRICT, int SHADE_CAP>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
     const int lane = lane_id();
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
     __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
     uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
-    __shared__ DevShade s_shade[SHADE_LDS ? RT_SHADE_LDS : 1];
+    __shared__ DevShade s_shade[SHADE_CAP > 0 ? SHADE_CAP : 1];
     const DevShade* shade = P.sc.shade;
-    if (SHADE_LDS) {  // every hit reads a few fields of its record, one after another
+    if (SHADE_CAP > 0) {  // every hit reads a few fields of its record, one after another
         const int words = P.sc.n_prims * (int)(sizeof(DevShade) / 4);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.sc.shade);
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_shade);
@@ -1506,9 +1507,10 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         uint64_t grid = (uint64_t)s->cus * bpc;
         const uint64_t want_blocks = ((uint64_t)P.n_paths + 255) / 256;
         if (grid > want_blocks) grid = want_blocks;
-        if (strict) hipLaunchKernelGGL((render_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
-        else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((render_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
-        else hipLaunchKernelGGL((render_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        if (strict) hipLaunchKernelGGL((render_kernel<true, 0>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        else if (P.sc.n_prims <= 16) hipLaunchKernelGGL((render_kernel<false, 16>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        else hipLaunchKernelGGL((render_kernel<false, 0>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, g_stream, P);
         HIPCHK(hipGetLastError());
