@@ -548,6 +548,110 @@ __global__ __launch_bounds__(256) void resolve_kernel(RenderParams P) {
     *reinterpret_cast<uint32_t*>(P.out + ((size_t)py * (size_t)P.tex_w + (size_t)px) * 4) = rgba;
 }
 
+// ---- four-wide tree built on the device ---------------------------------------------------------
+// The reference builds its tree on the CPU (median split with std::sort, CR/primitive.cpp:552-616) and the
+// pruned walk accepts any tree that loses no triangle (see mesh_walk4), so this builder is free to be simple:
+// the triangles are sorted by the Morton code of their centres and level l of a complete four-ary tree cuts
+// the sorted run into parts of 4^(levels - l) triangles (the last part may be short or missing).  Boxes are single precision, rounded outward, padded like the host
+// builder's.  Node (l, i) is stored at first + (4^l - 1) / 3 + i.
+DEV uint32_t morton_spread10(uint32_t v) {
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu, v = (v | (v << 8)) & 0x0300F00Fu, v = (v | (v << 4)) & 0x030C30C3u, v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+struct TriBounds {
+    double lo[3], hi[3];
+};
+DEV TriBounds tri_bounds(const rt_bvh_leaf& lf) {
+    TriBounds b;
+    const double v[3][3] = {{lf.O1.x, lf.O1.y, lf.O1.z}, {lf.O2.x, lf.O2.y, lf.O2.z}, {lf.O3.x, lf.O3.y, lf.O3.z}};
+#pragma unroll
+    for (int k = 0; k < 3; k++) b.lo[k] = fmin(v[0][k], fmin(v[1][k], v[2][k])), b.hi[k] = fmax(v[0][k], fmax(v[1][k], v[2][k]));
+    return b;
+}
+// keys[i] = Morton code of triangle i of the mesh << 32 | i; the tail up to a power of two sorts last
+__global__ void tree_keys_kernel(const rt_bvh_leaf* leaves, const uint32_t* mesh_leaves, uint32_t n, uint32_t n_pad, d3 lo, d3 inv_ext,
+                                 unsigned long long* keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i >= n) {
+        keys[i] = ~0ull;
+        return;
+    }
+    const TriBounds b = tri_bounds(leaves[mesh_leaves[i]]);
+    const double c[3] = {0.5 * (b.lo[0] + b.hi[0]), 0.5 * (b.lo[1] + b.hi[1]), 0.5 * (b.lo[2] + b.hi[2])};
+    const double l3[3] = {lo.x, lo.y, lo.z}, e3[3] = {inv_ext.x, inv_ext.y, inv_ext.z};
+    uint32_t code = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double q = (c[k] - l3[k]) * e3[k] * 1024.0;
+        q = q >= 0.0 ? q : 0.0;  // also catches NaN
+        const uint32_t cell = q < 1023.0 ? (uint32_t)q : 1023u;
+        code |= morton_spread10(cell) << k;
+    }
+    keys[i] = ((unsigned long long)code << 32) | i;
+}
+// one compare-exchange pass of a bitonic sorting network over n_pad = 2^m keys
+__global__ void tree_sort_pass_kernel(unsigned long long* keys, uint32_t n_pad, uint32_t j, uint32_t k) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    const uint32_t p = i ^ j;
+    if (p <= i) return;
+    const unsigned long long a = keys[i], b = keys[p];
+    const bool up = (i & k) == 0;
+    if ((a > b) == up) keys[i] = b, keys[p] = a;
+}
+// single-precision box of the triangle at every sorted position, and its leaf index
+__global__ void tree_boxes_kernel(const rt_bvh_leaf* leaves, const uint32_t* mesh_leaves, const unsigned long long* keys, uint32_t n,
+                                  float* boxes, uint32_t* sorted_leaf) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t leaf = mesh_leaves[(uint32_t)keys[p]];
+    const TriBounds b = tri_bounds(leaves[leaf]);
+    sorted_leaf[p] = leaf;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        // a triangle accepted by the double-precision test may lie a rounding error outside its exact bounds
+        const double pad = 1e-9 * (1.0 + fabs(b.lo[k]) + fabs(b.hi[k])) + 1e-7 * (b.hi[k] - b.lo[k]);
+        boxes[p * 6 + k] = __double2float_rd(b.lo[k] - pad);
+        boxes[p * 6 + 3 + k] = __double2float_ru(b.hi[k] + pad);
+    }
+}
+// child c of node i of one level: a triangle, an interior node of the level below (already built), or nothing
+__global__ void tree_level_kernel(DevNode4* nodes, uint32_t first, int level, int levels, uint32_t n, const float* boxes,
+                                  const uint32_t* sorted_leaf) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_level = 1u << (2 * level);  // nodes of this level
+    if (t >= per_level * 4u) return;
+    const uint32_t i = t >> 2, c = t & 3u;
+    const uint32_t off = (per_level - 1u) / 3u, off_below = (per_level * 4u - 1u) / 3u;
+#ifdef RT_TREE_EQUAL_RUNS
+    const unsigned long long parts = (unsigned long long)per_level * 4ull;  // runs of the level below
+    const uint32_t b = (uint32_t)((unsigned long long)t * n / parts), e = (uint32_t)((unsigned long long)(t + 1u) * n / parts);
+#else
+    // left-packed: a child of this level spans 4^(levels - 1 - level) sorted triangles, so the lowest nodes are full
+    const unsigned long long span = 1ull << (2 * (levels - 1 - level));
+    const uint32_t b = (uint32_t)std::min<unsigned long long>(n, t * span), e = (uint32_t)std::min<unsigned long long>(n, (t + 1ull) * span);
+#endif
+    DevNode4& nd = nodes[first + off + i];
+    float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t ref = RT_REF_END;
+    if (e - b == 1u) {
+        ref = RT_REF_LEAF | sorted_leaf[b];
+        for (int k = 0; k < 3; k++) lo[k] = boxes[b * 6 + k], hi[k] = boxes[b * 6 + 3 + k];
+    } else if (e - b > 1u) {
+        ref = first + off_below + t;
+        const DevNode4& ch = nodes[ref];
+        for (int k = 0; k < 3; k++) lo[k] = __builtin_inff(), hi[k] = -__builtin_inff();
+        for (int cc = 0; cc < 4; cc++) {
+            if (ch.child[cc] == RT_REF_END) continue;
+            for (int k = 0; k < 3; k++) lo[k] = fminf(lo[k], ch.lo[k][cc]), hi[k] = fmaxf(hi[k], ch.hi[k][cc]);
+        }
+    }
+    for (int k = 0; k < 3; k++) nd.lo[k][c] = lo[k], nd.hi[k][c] = hi[k];
+    nd.child[c] = ref;
+}
+
 // ---- debug kernel: primary ray of every pixel, reference-order walk with a visit log ------------
 struct ProbeParams {
     DevScene sc;
@@ -607,6 +711,7 @@ struct rt_scene {
     int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int desc_cam_w = 0, desc_cam_h = 0;
+    float tree_build_ms = 0.0f;  // device time of the four-wide tree build, 0 if the host built the trees
 };
 
 extern "C" int rt_init(int device) {
@@ -727,11 +832,20 @@ static float round_up(double x) {
     return (double)f < x ? std::nextafterf(f, INFINITY) : f;
 }
 
+struct TreeJob {  // one mesh whose four-wide tree is built on the device, in place, after the slab has been uploaded
+    uint32_t first;                 // index of its root DevNode4
+    int levels;                     // node levels; level l holds 4^l nodes, stored level after level
+    double lo[3], hi[3];            // bounds of the mesh (Morton code frame)
+    std::vector<uint32_t> leaves;   // leaf indices of its triangles
+};
 struct Tree4 {
     std::vector<DevNode4> nodes;
     std::vector<uint32_t> node_parent, leaf_parent;   // per binary node / per leaf
     std::vector<int32_t> mesh_root4;                  // per mesh: root DevNode4 index, -1 = use the stackless walk
+    std::vector<TreeJob> jobs;
 };
+static int g_tree_builder = 0;  // 0 = host (binned surface-area heuristic), 1 = device (Morton order, balanced)
+static bool g_tree_builder_set = false;
 
 // double-precision bounds of what hangs under a child ref: the reference's box of an interior node, the
 // triangle's own bounds for a leaf
@@ -831,8 +945,9 @@ static size_t sah_split(std::vector<SahTri>& tris, size_t b, size_t e, bool bala
     return (m == b || m == e) ? median() : m;
 }
 
-static void build_tree4(const rt_scene_desc* d, Tree4& T) {
+static void build_tree4(const rt_scene_desc* d, Tree4& T, bool device_build) {
     T.nodes.clear();
+    T.jobs.clear();
     T.node_parent.assign(d->n_nodes, RT_REF_END);
     T.leaf_parent.assign(d->n_leaves, RT_REF_END);
     T.mesh_root4.assign(d->n_meshes, -1);
@@ -886,6 +1001,23 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T) {
         double cap = 1;
         for (int i = 0; i < MAX_LEVELS; i++) cap *= 4;
         if ((double)tris.size() > cap) continue;
+        if (device_build) {
+            // complete four-ary tree over the triangles in Morton order: level l splits them into 4^l equal runs
+            TreeJob job;
+            job.first = (uint32_t)T.nodes.size();
+            job.levels = 1;
+            for (double c4 = 4; c4 < (double)tris.size(); c4 *= 4) job.levels++;
+            ref_bounds(d, root, job.lo, job.hi);
+            job.leaves.reserve(tris.size());
+            for (const SahTri& t : tris) job.leaves.push_back(t.leaf & ~RT_REF_LEAF);
+            size_t n_nodes = 0, per_level = 1;
+            for (int l = 0; l < job.levels; l++, per_level *= 4) n_nodes += per_level;
+            if (T.nodes.size() + n_nodes >= (1u << 30)) continue;
+            T.nodes.resize(T.nodes.size() + n_nodes);  // zero-filled here, written by the device
+            T.mesh_root4[mi] = (int32_t)job.first;
+            T.jobs.push_back(std::move(job));
+            continue;
+        }
 
         struct Item {
             size_t b, e;
@@ -1292,6 +1424,82 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     delete s;
 }
 
+// which builder makes the four-wide trees of rt_scene_create: the last rt_set_tree_builder call, else the
+// environment variable RT_AMD_TREE_BUILD ("device" or "host"), else the host builder
+static int tree_builder_choice() {
+    if (g_tree_builder_set) return g_tree_builder;
+    const char* e = std::getenv("RT_AMD_TREE_BUILD");
+    return (e && std::strcmp(e, "device") == 0) ? 1 : 0;
+}
+extern "C" int rt_set_tree_builder(int which) {
+    if (which != 0 && which != 1) return rt_fail(RT_ERR_INVALID, "rt_set_tree_builder: 0 = host, 1 = device");
+    g_tree_builder = which, g_tree_builder_set = true;
+    return RT_OK;
+}
+
+extern "C" double rt_scene_tree_build_ms(const rt_scene* s) { return s ? (double)s->tree_build_ms : 0.0; }
+
+// Build the trees of T.jobs in place (nodes4 and leaves point into the uploaded slab).
+static int run_tree_jobs(const Tree4& T, DevNode4* nodes4, const rt_bvh_leaf* leaves, float* build_ms) {
+    *build_ms = 0.0f;
+    if (T.jobs.empty()) return RT_OK;
+    size_t n_max = 0;
+    for (const TreeJob& j : T.jobs) n_max = std::max(n_max, j.leaves.size());
+    size_t pad_max = 1;
+    while (pad_max < n_max) pad_max <<= 1;
+    uint32_t *mesh_leaves = nullptr, *sorted_leaf = nullptr;
+    unsigned long long* keys = nullptr;
+    float* boxes = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Free {
+        uint32_t *&a, *&b;
+        unsigned long long*& c;
+        float*& d;
+        hipEvent_t &e0, &e1;
+        ~Free() {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            if (c) (void)hipFree(c);
+            if (d) (void)hipFree(d);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } guard{mesh_leaves, sorted_leaf, keys, boxes, e0, e1};
+    HIPCHK(hipMalloc(&mesh_leaves, n_max * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&sorted_leaf, n_max * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&keys, pad_max * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&boxes, n_max * 6 * sizeof(float)));
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g_stream));
+    for (const TreeJob& j : T.jobs) {
+        const uint32_t n = (uint32_t)j.leaves.size();
+        uint32_t n_pad = 1;
+        while (n_pad < n) n_pad <<= 1;
+        HIPCHK(hipMemcpyAsync(mesh_leaves, j.leaves.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, g_stream));
+        d3 lo = d3{j.lo[0], j.lo[1], j.lo[2]}, inv;
+        inv.x = j.hi[0] > j.lo[0] ? 1.0 / (j.hi[0] - j.lo[0]) : 0.0;
+        inv.y = j.hi[1] > j.lo[1] ? 1.0 / (j.hi[1] - j.lo[1]) : 0.0;
+        inv.z = j.hi[2] > j.lo[2] ? 1.0 / (j.hi[2] - j.lo[2]) : 0.0;
+        const unsigned tpb = 256;
+        hipLaunchKernelGGL(tree_keys_kernel, dim3((n_pad + tpb - 1) / tpb), dim3(tpb), 0, g_stream, leaves, mesh_leaves, n, n_pad, lo, inv, keys);
+        for (uint32_t k = 2; k <= n_pad; k <<= 1)
+            for (uint32_t jj = k >> 1; jj > 0; jj >>= 1)
+                hipLaunchKernelGGL(tree_sort_pass_kernel, dim3((n_pad + tpb - 1) / tpb), dim3(tpb), 0, g_stream, keys, n_pad, jj, k);
+        hipLaunchKernelGGL(tree_boxes_kernel, dim3((n + tpb - 1) / tpb), dim3(tpb), 0, g_stream, leaves, mesh_leaves, keys, n, boxes, sorted_leaf);
+        for (int l = j.levels - 1; l >= 0; l--) {
+            const uint32_t threads = 4u << (2 * l);
+            hipLaunchKernelGGL(tree_level_kernel, dim3((threads + tpb - 1) / tpb), dim3(tpb), 0, g_stream, nodes4, j.first, l, j.levels, n, boxes, sorted_leaf);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));  // mesh_leaves is reused by the next mesh
+    }
+    HIPCHK(hipEventRecord(e1, g_stream));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(build_ms, e0, e1));
+    return RT_OK;
+}
+
 extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (!out) return rt_fail(RT_ERR_INVALID, "rt_scene_create: null out pointer");
     *out = nullptr;
@@ -1313,7 +1521,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<DevGeom> geom((size_t)d->n_primitives), segs;
     std::vector<uint32_t> tex_off((size_t)d->n_textures);
     Tree4 T;
-    build_tree4(d, T);
+    build_tree4(d, T, tree_builder_choice() == 1);
     size_t texel_bytes = 0;
     for (int i = 0; i < d->n_textures; i++) {
         tex_off[i] = (uint32_t)texel_bytes;
@@ -1366,6 +1574,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HIPCHK(hipMalloc(&s->slab, s->slab_bytes));
     HIPCHK(hipMemcpy(s->slab, host.data(), s->slab_bytes, hipMemcpyHostToDevice));
     uint8_t* base = (uint8_t*)s->slab;
+    rc = run_tree_jobs(T, (DevNode4*)(base + off_n2), (const rt_bvh_leaf*)(base + off_f), &s->tree_build_ms);
+    if (rc) return rc;
     DevScene& v = s->dev;
     v.bg_top = d3{d->background_top.x, d->background_top.y, d->background_top.z};
     v.bg_bottom = d3{d->background_bottom.x, d->background_bottom.y, d->background_bottom.z};

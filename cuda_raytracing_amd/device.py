@@ -13,15 +13,22 @@ from . import abi
 
 
 class DeviceScene:
-    def __init__(self, host_scene, device=0):
+    def __init__(self, host_scene, device=0, tree_builder=None):
+        """tree_builder: None = the library's default, "host" or "device" (rt_set_tree_builder)."""
         import torch  # noqa: F401  plumbing: loads the HIP runtime that librt_amd.so then binds to
 
         self._lib = abi.load_library()
         abi.check(self._lib.rt_init(device))
+        if tree_builder is not None:
+            abi.check(self._lib.rt_set_tree_builder({"host": 0, "device": 1}[tree_builder]))
         self.device = device
         self._h = C.c_void_p()
         abi.check(self._lib.rt_scene_create(host_scene.desc_ptr, C.byref(self._h)))
         self.host = host_scene
+
+    @property
+    def tree_build_ms(self):
+        return float(self._lib.rt_scene_tree_build_ms(self._h))
 
     def close(self):
         if self._h:

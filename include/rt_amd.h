@@ -230,6 +230,16 @@ int rt_init(int device);
 /* Render on `stream` (a hipStream_t cast to void*, NULL = the null stream) from now on. */
 int rt_set_stream(void* hip_stream);
 
+/* Who builds the four-wide trees the pruned traversal walks, from the next rt_scene_create on:
+ * 0 = the host (binned surface-area heuristic, the default), 1 = the device (triangles in Morton
+ * order under a complete four-ary tree; a few ms instead of tens, somewhat slower to walk).  The
+ * image does not depend on the choice.  The reference builds its one tree on the CPU
+ * (CR/primitive.cpp:552-616, kept as it is for parity) and has no device builder; without a call
+ * the environment variable RT_AMD_TREE_BUILD=device|host decides. */
+int rt_set_tree_builder(int which);
+/* Device time of the last scene's tree build in ms (0 when the host built the trees). */
+double rt_scene_tree_build_ms(const rt_scene* scene);
+
 /* Upload a scene: one slab, one copy.  Replaces createCudaSceneFromCPUScene
  * (CR/Renderer_CUDA.cpp:298-335). */
 int rt_scene_create(const rt_scene_desc* desc, rt_scene** out);
