@@ -551,9 +551,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(RenderParams P) {
 // ---- four-wide tree built on the device ---------------------------------------------------------
 // The reference builds its tree on the CPU (median split with std::sort, CR/primitive.cpp:552-616) and the
 // pruned walk accepts any tree that loses no triangle (see mesh_walk4), so this builder is free to be simple:
-// the triangles are sorted by the Morton code of their centres and level l of a complete four-ary tree cuts
-// the sorted run into parts of 4^(levels - l) triangles (the last part may be short or missing).  Boxes are single precision, rounded outward, padded like the host
-// builder's.  Node (l, i) is stored at first + (4^l - 1) / 3 + i.
+// the triangles are sorted by the Morton code of their centres and the sorted run is cut top-down where the code changes
+// in its highest varying bit (a linear BVH, collapsed two binary levels at a time), at most max_levels levels deep.
+// Boxes are single precision, rounded outward, padded like the host builder's.
 DEV uint32_t morton_spread10(uint32_t v) {
     v &= 1023u;
     v = (v | (v << 16)) & 0x030000FFu, v = (v | (v << 8)) & 0x0300F00Fu, v = (v | (v << 4)) & 0x030C30C3u, v = (v | (v << 2)) & 0x09249249u;
@@ -617,39 +617,85 @@ __global__ void tree_boxes_kernel(const rt_bvh_leaf* leaves, const uint32_t* mes
         boxes[p * 6 + 3 + k] = __double2float_ru(b.hi[k] + pad);
     }
 }
-// child c of node i of one level: a triangle, an interior node of the level below (already built), or nothing
-__global__ void tree_level_kernel(DevNode4* nodes, uint32_t first, int level, int levels, uint32_t n, const float* boxes,
-                                  const uint32_t* sorted_leaf) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t per_level = 1u << (2 * level);  // nodes of this level
-    if (t >= per_level * 4u) return;
-    const uint32_t i = t >> 2, c = t & 3u;
-    const uint32_t off = (per_level - 1u) / 3u, off_below = (per_level * 4u - 1u) / 3u;
-#ifdef RT_TREE_EQUAL_RUNS
-    const unsigned long long parts = (unsigned long long)per_level * 4ull;  // runs of the level below
-    const uint32_t b = (uint32_t)((unsigned long long)t * n / parts), e = (uint32_t)((unsigned long long)(t + 1u) * n / parts);
-#else
-    // left-packed: a child of this level spans 4^(levels - 1 - level) sorted triangles, so the lowest nodes are full
-    const unsigned long long span = 1ull << (2 * (levels - 1 - level));
-    const uint32_t b = (uint32_t)std::min<unsigned long long>(n, t * span), e = (uint32_t)std::min<unsigned long long>(n, (t + 1ull) * span);
-#endif
-    DevNode4& nd = nodes[first + off + i];
-    float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
-    uint32_t ref = RT_REF_END;
-    if (e - b == 1u) {
-        ref = RT_REF_LEAF | sorted_leaf[b];
-        for (int k = 0; k < 3; k++) lo[k] = boxes[b * 6 + k], hi[k] = boxes[b * 6 + 3 + k];
-    } else if (e - b > 1u) {
-        ref = first + off_below + t;
+// Work list of the top-down pass: the interior nodes, level after level (level l = items [level_off[l], level_off[l + 1])).
+struct TreeItem {
+    uint32_t node, b, e;  // DevNode4 index, and its run [b, e) of sorted triangles (e - b >= 2)
+};
+struct TreeState {
+    uint32_t next_node, tail;  // next free DevNode4 index, items appended so far
+    uint32_t level_off[32];
+};
+// first index in [b, e) whose Morton code has the highest bit in which the codes of the run differ; the middle if all agree
+DEV uint32_t tree_split_point(const unsigned long long* keys, uint32_t b, uint32_t e) {
+    const uint32_t cb = (uint32_t)(keys[b] >> 32), ce = (uint32_t)(keys[e - 1] >> 32);
+    if (cb == ce) return b + (e - b) / 2;
+    const uint32_t bit = 1u << (31 - __clz(cb ^ ce));
+    uint32_t lo = b, hi = e - 1;  // code[lo] has the bit clear, code[hi] has it set
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((uint32_t)(keys[mid] >> 32) & bit) hi = mid;
+        else lo = mid;
+    }
+    return hi;
+}
+// One level of the top-down pass, one thread per interior node: its run is cut where the Morton code changes in its
+// highest varying bit, and both halves once more, which gives up to four children (cells of the Morton grid, like a
+// linear BVH collapsed two levels at a time).  A child may not hold more triangles than the levels left below it can
+// take (4 per node of the last level); a cut that breaks that rule is replaced by four equal parts.
+__global__ void tree_split_kernel(DevNode4* nodes, TreeItem* items, TreeState* st, int level, int max_levels, const unsigned long long* keys,
+                                  const float* boxes, const uint32_t* sorted_leaf) {
+    const uint32_t i = st->level_off[level] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= st->level_off[level + 1]) return;
+    const TreeItem it = items[i];
+    const unsigned long long child_cap = 1ull << (2 * (max_levels - level - 1));
+    uint32_t cut[5] = {it.b, it.b, it.b, it.e, it.e};  // child c = [cut[c], cut[c + 1]), empty ones allowed
+    {
+        const uint32_t m = tree_split_point(keys, it.b, it.e);
+        cut[2] = m;
+        cut[1] = m - it.b >= 2 ? tree_split_point(keys, it.b, m) : it.b;
+        cut[3] = it.e - m >= 2 ? tree_split_point(keys, m, it.e) : it.e;
+        bool fits = true;
+        for (int c = 0; c < 4; c++) fits = fits && (unsigned long long)(cut[c + 1] - cut[c]) <= child_cap;
+        if (!fits) {
+            const uint32_t n = it.e - it.b;
+            for (int c = 1; c < 4; c++) cut[c] = it.b + (uint32_t)((unsigned long long)n * c / 4);
+        }
+    }
+    DevNode4& nd = nodes[it.node];
+    for (int c = 0; c < 4; c++) {
+        const uint32_t b = cut[c], e = cut[c + 1];
+        uint32_t ref = RT_REF_END;
+        float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
+        if (e - b == 1u) {
+            ref = RT_REF_LEAF | sorted_leaf[b];
+            for (int k = 0; k < 3; k++) lo[k] = boxes[b * 6 + k], hi[k] = boxes[b * 6 + 3 + k];
+        } else if (e - b > 1u) {
+            ref = atomicAdd(&st->next_node, 1u);
+            items[atomicAdd(&st->tail, 1u)] = TreeItem{ref, b, e};
+        }
+        for (int k = 0; k < 3; k++) nd.lo[k][c] = lo[k], nd.hi[k][c] = hi[k];  // interior children: filled in by tree_box_kernel
+        nd.child[c] = ref;
+    }
+}
+__global__ void tree_mark_level_kernel(TreeState* st, int level) { st->level_off[level] = st->tail; }
+// bottom-up pass, one thread per interior node of a level: the box of an interior child is the union of that child's own
+// child boxes, which the levels below have already written
+__global__ void tree_box_kernel(DevNode4* nodes, const TreeItem* items, const TreeState* st, int level) {
+    const uint32_t i = st->level_off[level] + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= st->level_off[level + 1]) return;
+    DevNode4& nd = nodes[items[i].node];
+    for (int c = 0; c < 4; c++) {
+        const uint32_t ref = nd.child[c];
+        if (ref == RT_REF_END || (ref & RT_REF_LEAF)) continue;
         const DevNode4& ch = nodes[ref];
+        float lo[3], hi[3];
         for (int k = 0; k < 3; k++) lo[k] = __builtin_inff(), hi[k] = -__builtin_inff();
         for (int cc = 0; cc < 4; cc++) {
             if (ch.child[cc] == RT_REF_END) continue;
             for (int k = 0; k < 3; k++) lo[k] = fminf(lo[k], ch.lo[k][cc]), hi[k] = fmaxf(hi[k], ch.hi[k][cc]);
         }
+        for (int k = 0; k < 3; k++) nd.lo[k][c] = lo[k], nd.hi[k][c] = hi[k];
     }
-    for (int k = 0; k < 3; k++) nd.lo[k][c] = lo[k], nd.hi[k][c] = hi[k];
-    nd.child[c] = ref;
 }
 
 // ---- debug kernel: primary ray of every pixel, reference-order walk with a visit log ------------
@@ -833,8 +879,7 @@ static float round_up(double x) {
 }
 
 struct TreeJob {  // one mesh whose four-wide tree is built on the device, in place, after the slab has been uploaded
-    uint32_t first;                 // index of its root DevNode4
-    int levels;                     // node levels; level l holds 4^l nodes, stored level after level
+    uint32_t first;                 // index of its root DevNode4; its nodes are first .. first + number of triangles - 1 at most
     double lo[3], hi[3];            // bounds of the mesh (Morton code frame)
     std::vector<uint32_t> leaves;   // leaf indices of its triangles
 };
@@ -1002,18 +1047,14 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T, bool device_build) {
         for (int i = 0; i < MAX_LEVELS; i++) cap *= 4;
         if ((double)tris.size() > cap) continue;
         if (device_build) {
-            // complete four-ary tree over the triangles in Morton order: level l splits them into 4^l equal runs
+            // every interior node has at least two children, so a mesh of n triangles needs fewer than n nodes
             TreeJob job;
             job.first = (uint32_t)T.nodes.size();
-            job.levels = 1;
-            for (double c4 = 4; c4 < (double)tris.size(); c4 *= 4) job.levels++;
             ref_bounds(d, root, job.lo, job.hi);
             job.leaves.reserve(tris.size());
             for (const SahTri& t : tris) job.leaves.push_back(t.leaf & ~RT_REF_LEAF);
-            size_t n_nodes = 0, per_level = 1;
-            for (int l = 0; l < job.levels; l++, per_level *= 4) n_nodes += per_level;
-            if (T.nodes.size() + n_nodes >= (1u << 30)) continue;
-            T.nodes.resize(T.nodes.size() + n_nodes);  // zero-filled here, written by the device
+            if (T.nodes.size() + tris.size() >= (1u << 30)) continue;
+            T.nodes.resize(T.nodes.size() + tris.size());  // zero-filled here, written by the device
             T.mesh_root4[mi] = (int32_t)job.first;
             T.jobs.push_back(std::move(job));
             continue;
@@ -1450,25 +1491,33 @@ static int run_tree_jobs(const Tree4& T, DevNode4* nodes4, const rt_bvh_leaf* le
     uint32_t *mesh_leaves = nullptr, *sorted_leaf = nullptr;
     unsigned long long* keys = nullptr;
     float* boxes = nullptr;
+    TreeItem* items = nullptr;
+    TreeState* state = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     struct Free {
         uint32_t *&a, *&b;
         unsigned long long*& c;
         float*& d;
+        TreeItem*& it;
+        TreeState*& st;
         hipEvent_t &e0, &e1;
         ~Free() {
             if (a) (void)hipFree(a);
             if (b) (void)hipFree(b);
             if (c) (void)hipFree(c);
             if (d) (void)hipFree(d);
+            if (it) (void)hipFree(it);
+            if (st) (void)hipFree(st);
             if (e0) (void)hipEventDestroy(e0);
             if (e1) (void)hipEventDestroy(e1);
         }
-    } guard{mesh_leaves, sorted_leaf, keys, boxes, e0, e1};
+    } guard{mesh_leaves, sorted_leaf, keys, boxes, items, state, e0, e1};
     HIPCHK(hipMalloc(&mesh_leaves, n_max * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&sorted_leaf, n_max * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&keys, pad_max * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&boxes, n_max * 6 * sizeof(float)));
+    HIPCHK(hipMalloc(&items, n_max * sizeof(TreeItem)));
+    HIPCHK(hipMalloc(&state, sizeof(TreeState)));
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, g_stream));
@@ -1487,10 +1536,21 @@ static int run_tree_jobs(const Tree4& T, DevNode4* nodes4, const rt_bvh_leaf* le
             for (uint32_t jj = k >> 1; jj > 0; jj >>= 1)
                 hipLaunchKernelGGL(tree_sort_pass_kernel, dim3((n_pad + tpb - 1) / tpb), dim3(tpb), 0, g_stream, keys, n_pad, jj, k);
         hipLaunchKernelGGL(tree_boxes_kernel, dim3((n + tpb - 1) / tpb), dim3(tpb), 0, g_stream, leaves, mesh_leaves, keys, n, boxes, sorted_leaf);
-        for (int l = j.levels - 1; l >= 0; l--) {
-            const uint32_t threads = 4u << (2 * l);
-            hipLaunchKernelGGL(tree_level_kernel, dim3((threads + tpb - 1) / tpb), dim3(tpb), 0, g_stream, nodes4, j.first, l, j.levels, n, boxes, sorted_leaf);
+        constexpr int MAX_LEVELS = RT_STACK / 3;  // the walk pushes up to three siblings per level
+        TreeState init;
+        std::memset(&init, 0, sizeof(init));
+        init.next_node = j.first + 1, init.tail = 1, init.level_off[1] = 1;
+        const TreeItem root_item{j.first, 0u, n};
+        HIPCHK(hipMemcpyAsync(state, &init, sizeof(init), hipMemcpyHostToDevice, g_stream));
+        HIPCHK(hipMemcpyAsync(items, &root_item, sizeof(root_item), hipMemcpyHostToDevice, g_stream));
+        // a level has at most n / 2 interior nodes; its true size is read from the state on the device
+        const unsigned level_blocks = (n / 2 + tpb) / tpb;
+        for (int l = 0; l < MAX_LEVELS; l++) {
+            hipLaunchKernelGGL(tree_split_kernel, dim3(level_blocks), dim3(tpb), 0, g_stream, nodes4, items, state, l, MAX_LEVELS, keys, boxes, sorted_leaf);
+            hipLaunchKernelGGL(tree_mark_level_kernel, dim3(1), dim3(1), 0, g_stream, state, l + 2);
         }
+        for (int l = MAX_LEVELS - 1; l >= 0; l--)
+            hipLaunchKernelGGL(tree_box_kernel, dim3(level_blocks), dim3(tpb), 0, g_stream, nodes4, items, state, l);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(g_stream));  // mesh_leaves is reused by the next mesh
     }

@@ -232,7 +232,7 @@ int rt_set_stream(void* hip_stream);
 
 /* Who builds the four-wide trees the pruned traversal walks, from the next rt_scene_create on:
  * 0 = the host (binned surface-area heuristic, the default), 1 = the device (triangles in Morton
- * order under a complete four-ary tree; a few ms instead of tens, somewhat slower to walk).  The
+ * order, cut top-down where the code changes; a few ms instead of tens, somewhat slower to walk).  The
  * image does not depend on the choice.  The reference builds its one tree on the CPU
  * (CR/primitive.cpp:552-616, kept as it is for parity) and has no device builder; without a call
  * the environment variable RT_AMD_TREE_BUILD=device|host decides. */
