@@ -33,14 +33,14 @@ def algorithmic_bytes(s):
             + 4 * s.pixels + 128 * s.shaded_hits + 16 * s.texture_fetches)
 
 
-def cpu_baseline(hs, st, width, height, budget_s=20.0):
+def cpu_baseline(hs, st, width, height, budget_s=25.0):
     """Oracle (port of the reference algorithm) on a lattice of 32x32 blocks of the same frame, about budget_s of CPU work."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as orc
 
     lib = orc.load()
     cores = lib.orc_max_threads()
-    nx, ny, b = 12, 8, 32
+    nx, ny, b = 16, 12, 32
     rects = [(int((i + 0.5) * width / nx) - b // 2, int((j + 0.5) * height / ny) - b // 2, b, b) for j in range(ny) for i in range(nx)]
     # blocks in an order that covers the frame evenly however early the budget ends: every 8th, then every 4th, ...
     order, seen = [], set()
@@ -75,7 +75,7 @@ def measured_traffic():
         return None, None
     note = ("FETCH_SIZE + WRITE_SIZE (KiB -> bytes) of one launch, profiles/current/. FETCH_SIZE is taken as reported: the reads are "
             "4-byte-per-lane scratch reloads and 16-byte-per-lane gathers, widths for which the gfx950 half-count of wide streaming "
-            "reads is not calibrated; at most 2x the fetch part. Nearly all of it is register-spill and path-state scratch, not scene data.")
+            "reads is not calibrated; at most 2x the fetch part. Nearly all of it is register-spill scratch and the path colours handed to the resolve kernel (3.2 GB), not scene data.")
     extra = {}
     try:
         sq = j["pmc_sq"]
