@@ -697,6 +697,13 @@ extern "C" int rt_host_scene_load(const char* scene_path, const char* asset_dir,
     d.camera.shade_quality = cam.shade_quality, d.camera.drefl_quality = cam.drefl_quality;
     d.camera.lens_W = cam.lens_W, d.camera.lens_H = cam.lens_H;
     finalize(*hs);
+    // Missing or unreadable textures: the reference's CUDA path renders the primitive untextured and its CPU path
+    // crashes (CR/bmp.cpp:133-150 indexes an empty image).  Default here: untextured plus a warning; with
+    // RT_AMD_STRICT_ASSETS=1 in the environment the load fails instead, naming the first such file.
+    if (!hs->warnings.empty()) {
+        const char* strict = std::getenv("RT_AMD_STRICT_ASSETS");
+        if (strict && strict[0] == '1') return rt_fail(RT_ERR_IO, hs->warnings.front());
+    }
     *out = hs.release();
     return RT_OK;
 }
