@@ -348,7 +348,7 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
             if (drained) break;
             continue;  // every slot just handed out lies outside its tile
         }
-        RT_LAP(ctr, PF_TASK);
+        RT_LAP(ctr, PF_REFILL);
 
         Hit h;
         h.prim = -1, h.leaf = -1, h.dist = RT_BIG_DIST, h.front = false, h.N = D3(0, 0, 0), h.C = D3(0, 0, 0);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
 #endif
     trace_stream<STRICT>(P, shade, ctr, stk);
 #ifdef RT_UTIL_COUNTERS
-    RT_LAP(ctr, PF_TASK);
+    RT_LAP(ctr, PF_REFILL);
     if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);
     unsigned long long v[CTR_ALL] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch,
                                      ctr.u_shadow_slots, ctr.u_shadow_items, ctr.u_trace_slots, ctr.u_trace_active,
@@ -937,7 +937,7 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
                  100.0 * c[CTR_U_TRACE_ACTIVE] / (double)(c[CTR_U_TRACE_SLOTS] ? c[CTR_U_TRACE_SLOTS] : 1), c[CTR_U_TRACE_ACTIVE], c[CTR_U_TRACE_SLOTS]);
     static const char* const probe_name[6] = {"shadow mesh walks", "closest mesh walks", "shadow interior steps", "shadow leaf steps",
                                               "closest interior steps", "closest leaf steps"};
-    static const char* const sect[PF_COUNT] = {"task setup / resolve", "frame pop / hand-back", "closest: analytic prims", "closest: mesh walk", "shade setup + texture",
+    static const char* const sect[PF_COUNT] = {"new paths (refill)", "frame pop / hand-back", "closest: analytic prims", "closest: mesh walk", "shade setup + texture",
                                                "light candidates", "chunk shuffles + counts", "rng + light sample", "shadow: analytic prims", "shadow: mesh walk",
                                                "shade math", "child ray set-up"};
     unsigned long long tot = 0;

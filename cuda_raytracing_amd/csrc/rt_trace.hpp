@@ -122,7 +122,7 @@ struct Counters {  // per-lane work counters, flushed once per wave
 #endif
 };
 // sections of the per-wave time profile (util builds)
-enum { PF_TASK = 0, PF_FRAME, PF_CLOSEST_PRIMS, PF_CLOSEST_MESH, PF_SHADE_SETUP, PF_CAND, PF_CHUNK_SHFL, PF_RNG, PF_SH_PRIMS, PF_SH_MESH,
+enum { PF_REFILL = 0, PF_FRAME, PF_CLOSEST_PRIMS, PF_CLOSEST_MESH, PF_SHADE_SETUP, PF_CAND, PF_CHUNK_SHFL, PF_RNG, PF_SH_PRIMS, PF_SH_MESH,
        PF_SHADE_MATH, PF_SPAWN, PF_COUNT };
 // lane-utilisation probe: counts this lane, and 64 slots once per wave-level execution
 #ifdef RT_UTIL_COUNTERS
