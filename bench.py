@@ -195,6 +195,9 @@ def main():
                                    f"{W}x{H}, {args.spp} spp, depth of field on (aperture 1, focal 1.35), semantics preset gpu_ref, pruned traversal",
                        "tile": args.tile, "partition": f"tile t -> rank t % {world}, gather to rank 0"},
         }
+        picked, plain_ms, shared_ms = ds.shared_walk
+        out["config"]["shadow_walk_variant"] = {"picked": {0: "plain", 1: "shared"}.get(picked, "plain (not timed)"),
+                                                "sample_ms_plain": plain_ms, "sample_ms_shared": shared_ms}
         kavg = kernel_ms / args.steps
         if strict_stats is not None:
             ab = algorithmic_bytes(strict_stats)

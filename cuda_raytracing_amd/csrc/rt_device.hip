@@ -73,6 +73,9 @@ struct RenderParams {
 #ifndef RT_LAUNCH_PATHS
 #define RT_LAUNCH_PATHS (1ull << 28)  // most paths of one launch (their colours take 24 bytes each: 6.4 GB); larger calls are cut into several launches
 #endif
+#ifndef RT_TUNE_BLOCKS
+#define RT_TUNE_BLOCKS 1024  // blocks per variant in the timing sample that picks the shadow-walk variant (2 M paths at 32 spp)
+#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 32  // idle lanes that trigger a refill: the set-up of new paths is long, and running it for one lane costs the same
                           // (measured ms/frame: 8: 52.0, 16: 49.1, 24: 47.7, 32: 47.1, 40: 47.3, 48: 47.8)
@@ -110,9 +113,9 @@ DEV uint32_t to_u8(double c) {
 
 // ---- CalnDiffusion for every lane that needs it, shadow rays dealt over the wave ---------------
 // CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
-template <bool STRICT>
+template <bool STRICT, bool SHARE>
 DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
-                      uint32_t pixel, uint32_t smp, Counters& ctr, uint32_t* stk) {
+                      uint32_t pixel, uint32_t smp, Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const DevScene& sc = P.sc;
     const int lane = lane_id();
     d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
@@ -202,8 +205,8 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             }
 #endif
             RT_LAP(ctr, PF_CHUNK_SHFL);
+            d3 target = d3{L.O.x, L.O.y, L.O.z};
             if (act) {
-                d3 target = d3{L.O.x, L.O.y, L.O.z};
 #ifdef RT_ABLATE_RNG
                 if (false) {
 #else
@@ -213,7 +216,11 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
                     frand_pair(P.k0, P.k1, opix, osmp, odraw + off + 2u * (uint32_t)si, fa, fb);
                     target = light_sample(L, fa, fb);
                 }
-                RT_LAP(ctr, PF_RNG);
+            }
+            RT_LAP(ctr, PF_RNG);
+            if (SHARE && stk != nullptr) {
+                clear = shadow_clear_shared(sc, P.flags, act, C, target, crashed, L.light_primitive, ocand, ctr, stk, xch);
+            } else if (act) {
                 clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, ctr, stk);
             }
             RT_LAP(ctr, PF_SH_PRIMS);
@@ -267,8 +274,8 @@ DEV uint32_t div_by(uint32_t n, uint32_t d, double inv) {
 
 // All paths of a launch.  The wave keeps up to 64 paths in flight, one per lane; lanes whose path has ended wait
 // until enough of them are idle, then take the next unstarted paths of the launch together ("path regeneration").
-template <bool STRICT>
-DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ctr, uint32_t* stk) {
+template <bool STRICT, bool SHARE>
+DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const DevScene& sc = P.sc;
     // frame k = the hit at depth k+1 that is waiting for a child ray to return
     double f_acc[RT_MAX_DEPTH][3], f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3], f_dist[RT_MAX_DEPTH];
@@ -382,7 +389,7 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
         }
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);
-        if (mask != 0ull) local = diffusion_coop<STRICT>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk);
+        if (mask != 0ull) local = diffusion_coop<STRICT, SHARE>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk, xch);
 
         if (tracing) {
             bool have_result = !surface;
@@ -489,7 +496,10 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
 // SHADE_CAP > 0: the shading table (at most SHADE_CAP primitives) is copied to LDS and read from there.  A template
 // parameter rather than a run-time choice so that the reads compile to LDS instructions, not to flat ones; two
 // capacities because a smaller LDS footprint measures 1 % faster on small scenes.
-template <bool STRICT, int SHADE_CAP>
+// SHARE: shadow rays walk the meshes with mesh_anyhit_shared (idle lanes take over parts of long walks).  Faster where
+// such walks dominate (c5_final: 265 -> 205 ms/frame), slower elsewhere because of the registers it takes (c4_lucy:
+// 44 -> 49 ms), so the host picks the variant per scene by timing both on part of a frame.
+template <bool STRICT, int SHADE_CAP, bool SHARE>
 __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
     const int lane = lane_id();
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
@@ -514,7 +524,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     ctr.prof = s_prof[threadIdx.x >> 6];
     if (lane < 1 + PF_COUNT) ctr.prof[lane] = lane == 0 ? __builtin_readcyclecounter() : 0ull;
 #endif
-    trace_stream<STRICT>(P, shade, ctr, stk);
+    // flags and exchange arrays of the shared any-hit walk, 3 * 64 words per wave
+    __shared__ uint32_t s_xch[SHARE ? 4 * 192 : 1];
+    uint32_t* xch = SHARE ? s_xch + (threadIdx.x >> 6) * 192 : nullptr;
+    trace_stream<STRICT, SHARE>(P, shade, ctr, stk, xch);
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_REFILL);
     if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);
@@ -604,6 +617,10 @@ struct rt_scene {
     size_t image_bytes = 0;
     double* path_out = nullptr;            // colours of the finished paths of one launch
     size_t path_out_bytes = 0;
+    int shared_walk = -1;                  // shadow mesh walks shared by the wave: -1 = not decided yet, 0 = no, 1 = yes
+    float tune_ms[2] = {0.0f, 0.0f};       // the timings behind that decision (plain, shared)
+    BlockRec* tune_blocks = nullptr;       // 2 * RT_TUNE_BLOCKS blocks: the two timing samples
+    hipEvent_t ev_tune[2] = {nullptr, nullptr};
     BlockRec* blocks = nullptr;            // 8x8 blocks of the tiles of the last call, in queue order
     size_t blocks_cap = 0, n_blocks = 0;
     std::vector<Tile> last_tiles;
@@ -695,6 +712,9 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (s->image) (void)hipFree(s->image);
     if (s->path_out) (void)hipFree(s->path_out);
     if (s->blocks) (void)hipFree(s->blocks);
+    if (s->tune_blocks) (void)hipFree(s->tune_blocks);
+    if (s->ev_tune[0]) (void)hipEventDestroy(s->ev_tune[0]);
+    if (s->ev_tune[1]) (void)hipEventDestroy(s->ev_tune[1]);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -792,6 +812,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.mesh_mask = 0;
     for (int i = 0; i < d->n_primitives && i < 64; i++)
         if (d->primitives[i].type == RT_PRIM_MESH) v.mesh_mask |= 1ull << i;
+    v.mesh_scale_max = 0.0;
+    for (int i = 0; i < d->n_primitives; i++)
+        if (geom[i].type == RT_PRIM_MESH && geom[i].aux2) v.mesh_scale_max = std::fmax(v.mesh_scale_max, geom[i].f[MSH_SCALE]);
     v.lights = (const rt_light*)(base + off_l);
     v.geom = (const DevGeom*)(base + off_g);
     v.segs = (const DevGeom*)(base + off_s);
@@ -811,6 +834,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * (CTR_ALL + 16)));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
+    HIPCHK(hipEventCreate(&s->ev_tune[0]));
+    HIPCHK(hipEventCreate(&s->ev_tune[1]));
+    HIPCHK(hipMalloc(&s->tune_blocks, 2 * RT_TUNE_BLOCKS * sizeof(BlockRec)));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     s->cus = prop.multiProcessorCount;
@@ -909,23 +935,63 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     P.k0 = (uint32_t)st->seed, P.k1 = (uint32_t)(st->seed >> 32), P.flags = st->flags;
     P.queue = s->queue, P.out = dst, P.counters = s->counters, P.path_out = s->path_out;
 
-    HIPCHK(hipEventRecord(s->ev0, g_stream));
-    for (uint64_t b0 = 0; b0 < blocks; b0 += chunk_blocks) {
-        const uint64_t nb = std::min(chunk_blocks, blocks - b0);
-        P.blocks = s->blocks + b0, P.n_blocks = (uint32_t)nb, P.n_paths = (uint32_t)(nb * block_paths);
+    // one launch: the blocks [first, first + nb) of `list`, traced and resolved
+    auto launch = [&](const BlockRec* list, uint64_t first, uint64_t nb, bool share) -> int {
+        P.blocks = list + first, P.n_blocks = (uint32_t)nb, P.n_paths = (uint32_t)(nb * block_paths);
         P.range_paths = (uint32_t)(((nb + 7) / 8) * block_paths);
         HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
         // persistent grid: every wave draws paths until the launch runs dry
         uint64_t grid = (uint64_t)s->cus * bpc;
         const uint64_t want_blocks = ((uint64_t)P.n_paths + 255) / 256;
         if (grid > want_blocks) grid = want_blocks;
-        if (strict) hipLaunchKernelGGL((render_kernel<true, 0>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
-        else if (P.sc.n_prims <= 16) hipLaunchKernelGGL((render_kernel<false, 16>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
-        else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
-        else hipLaunchKernelGGL((render_kernel<false, 0>), dim3((unsigned)grid), dim3(256), 0, g_stream, P);
+        const dim3 g((unsigned)grid), t(256);
+        if (strict) hipLaunchKernelGGL((render_kernel<true, 0, false>), g, t, 0, g_stream, P);
+        else if (P.sc.n_prims <= 16 && share) hipLaunchKernelGGL((render_kernel<false, 16, true>), g, t, 0, g_stream, P);
+        else if (P.sc.n_prims <= 16) hipLaunchKernelGGL((render_kernel<false, 16, false>), g, t, 0, g_stream, P);
+        else if (P.sc.n_prims <= RT_SHADE_LDS && share) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS, true>), g, t, 0, g_stream, P);
+        else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS, false>), g, t, 0, g_stream, P);
+        else hipLaunchKernelGGL((render_kernel<false, 0, false>), g, t, 0, g_stream, P);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, g_stream, P);
         HIPCHK(hipGetLastError());
+        return RT_OK;
+    };
+    HIPCHK(hipEventRecord(s->ev0, g_stream));
+    uint64_t done = 0;
+    // Which variant of the shadow mesh walk this scene gets is decided once, by timing: two equal samples of the frame's blocks
+    // (every other block of its first part) are rendered with one variant each; the rest of the frame and all later calls use
+    // the faster one.  Both variants give the same image, so the choice only costs two short launches.
+    if (!strict && s->shared_walk < 0) {
+        const char* e = std::getenv("RT_AMD_SHARED_WALK");
+        if (e && (e[0] == '0' || e[0] == '1')) s->shared_walk = e[0] - '0';
+        else if (s->dev.mesh_scale_max <= 0.0 || s->dev.n_prims > RT_SHADE_LDS) s->shared_walk = 0;  // nothing to share, or no variant built
+    }
+    const uint64_t sample = std::min<uint64_t>(std::min<uint64_t>(RT_TUNE_BLOCKS, chunk_blocks), blocks / 8);  // an eighth of the call at most, per variant
+    if (!strict && s->shared_walk < 0 && sample >= 128 && s->tune_blocks) {
+        std::vector<BlockRec> head(2 * sample), split(2 * sample);
+        HIPCHK(hipMemcpy(head.data(), s->blocks, head.size() * sizeof(BlockRec), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < sample; i++) split[i] = head[2 * i], split[sample + i] = head[2 * i + 1];
+        HIPCHK(hipMemcpy(s->tune_blocks, split.data(), split.size() * sizeof(BlockRec), hipMemcpyHostToDevice));
+        float ms[2] = {0.0f, 0.0f};
+        for (int round = 0; round < 2; round++) {  // the first round warms up caches, code and scratch; the second is timed
+            for (int v = 0; v < 2; v++) {
+                HIPCHK(hipEventRecord(s->ev_tune[0], g_stream));
+                int rc = launch(s->tune_blocks, v * sample, sample, v == 1);
+                if (rc) return rc;
+                HIPCHK(hipEventRecord(s->ev_tune[1], g_stream));
+                HIPCHK(hipEventSynchronize(s->ev_tune[1]));
+                HIPCHK(hipEventElapsedTime(&ms[v], s->ev_tune[0], s->ev_tune[1]));
+            }
+            if (round == 0) HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));  // its rays are not the frame's
+        }
+        s->shared_walk = ms[1] < 0.97f * ms[0] ? 1 : 0;  // the plain variant unless sharing is clearly faster
+        s->tune_ms[0] = ms[0], s->tune_ms[1] = ms[1];
+        done = 2 * sample;
+    }
+    const bool share = !strict && s->shared_walk == 1;
+    for (uint64_t b0 = done; b0 < blocks; b0 += chunk_blocks) {
+        int rc = launch(s->blocks, b0, std::min(chunk_blocks, blocks - b0), share);
+        if (rc) return rc;
     }
     HIPCHK(hipEventRecord(s->ev1, g_stream));
     unsigned long long c[CTR_ALL + 16];

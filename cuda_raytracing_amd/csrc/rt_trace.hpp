@@ -84,6 +84,7 @@ struct DevScene {
     d3 bg_top, bg_bottom, camO, camN, camDx, camDy;
     int32_t cam_w, cam_h, shade_n, n_lights, n_prims;
     unsigned long long mesh_mask;  // bit j set: primitive j (< 64) is a mesh
+    double mesh_scale_max;         // largest MSH_SCALE of the meshes that have a four-wide tree
     // Coarse answer to "which primitives can stand between a point and lamp l": a grid of RT_CGRID^3 cells over the
     // scene's bounded part, one 64-bit primitive mask per cell and lamp (null if the scene has more than 64 primitives).
     const unsigned long long* cand_grid;  // [lamp][z][y][x]
@@ -698,6 +699,150 @@ DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d
     return res;
 }
 
+// ---- any-hit walk shared by the wave ------------------------------------------------------------
+// Shadow rays of one wave end their walks at very different times, and a lane that is done would idle until the
+// longest walk of the wave ends.  Here an idle lane takes over part of a busy lane's walk instead: the busy lane
+// gives away the subtree on top of its stack, the idle lane copies the ray and walks that subtree.  Whoever finds
+// an occluding triangle raises the ray's flag; the answer for a ray is its flag, whichever lanes worked on it.
+// The set of subtrees walked for a ray is the same as in mesh_walk4<true> (less what a raised flag cuts short), and
+// every triangle goes through the same tests, so the answer is the same.
+// Must be called by all lanes of the wave that are active at the call site; `want` = this lane has a ray to test.
+// `xch` = 3 * 64 words of LDS of this wave: flags, and two exchange arrays.
+#ifndef RT_STEAL_MIN
+#define RT_STEAL_MIN 16  // idle lanes that make a round of hand-overs worth its cost
+#endif
+#ifndef RT_SHARE_STEPS
+#define RT_SHARE_STEPS 4  // interior steps between two looks at who is idle
+#endif
+// On entry the lane's stack (sp entries) holds the roots of the meshes its ray may enter; `S` = the largest mesh scale
+// of the scene (it only widens the error bounds).  The ray is passed by value and overwritten by hand-overs.
+DEV bool mesh_anyhit_shared(const DevScene& sc, double S, int sp, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk, uint32_t* xch) {
+    const int lane = lane_id();
+    uint32_t* flag = xch;
+    uint32_t* x_lane = xch + 64;
+    uint32_t* x_ref = xch + 128;
+    const bool enter = sp > 0;
+    if (__ballot(enter) == 0ull) return false;
+    flag[lane] = 0u;
+    // per-ray constants of the single-precision slab test (see mesh_walk4)
+    float ix, iy, iz, cx, cy, cz, M, tl;
+    {
+        const d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        ix = (float)inv.x, iy = (float)inv.y, iz = (float)inv.z;
+        cx = (float)(-(o.x * inv.x)), cy = (float)(-(o.y * inv.y)), cz = (float)(-(o.z * inv.z));
+        const double mm = fmax(fmax((S + fabs(o.x)) * fabs(inv.x), (S + fabs(o.y)) * fabs(inv.y)), (S + fabs(o.z)) * fabs(inv.z));
+        M = (float)(mm * 2.4e-7) * 1.000001f + 1e-30f;
+        tl = (float)t_limit;
+        tl = tl + fabsf(tl) * 2.4e-7f;
+    }
+    uint32_t ref = enter ? stk[(--sp) * 64] : RT_REF_END;
+    int ray = lane;  // the lane whose ray this lane is working on
+    RT_PROBE(ctr, 0);
+    for (;;) {
+        // a ray that somebody has found occluded needs no more work
+        if (ref != RT_REF_END && flag[ray] != 0u) ref = RT_REF_END, sp = 0;
+        const unsigned long long busy = __ballot(ref != RT_REF_END);
+        if (busy == 0ull) break;
+        // ---- hand-overs: the k-th idle lane takes the top of the stack of the k-th lane that has one ----
+        const unsigned long long givers = __ballot(ref != RT_REF_END && sp > 0);
+        const int n_idle = 64 - __popcll(busy), n_give = __popcll(givers);
+        if (n_idle >= RT_STEAL_MIN && n_give > 0) {
+            const bool giver = ref != RT_REF_END && sp > 0;
+            if (giver) {
+                const int k = rank_in(givers);
+                if (k < n_idle) {
+                    x_lane[k] = (uint32_t)lane;
+                    x_ref[k] = stk[(--sp) * 64];
+                }
+            }
+            const bool idle = ref == RT_REF_END;
+            const int k = rank_in(~busy);
+            const bool take = idle && k < n_give;
+            const int from = take ? (int)x_lane[k] : lane;
+            // the ray, from the lane that gives
+            o = shfl_d3(o, from), d = shfl_d3(d, from);
+            t_limit = shfl_d(t_limit, from);
+            ix = __shfl(ix, from, 64), iy = __shfl(iy, from, 64), iz = __shfl(iz, from, 64);
+            cx = __shfl(cx, from, 64), cy = __shfl(cy, from, 64), cz = __shfl(cz, from, 64);
+            M = __shfl(M, from, 64), tl = __shfl(tl, from, 64);
+            ray = __shfl(ray, from, 64);
+            if (take) ref = x_ref[k];
+        }
+        // ---- a few interior steps ----
+#pragma unroll 1
+        for (int step = 0; step < RT_SHARE_STEPS; step++) {
+            const bool interior = ref != RT_REF_END && !(ref & RT_REF_LEAF);
+            if (__ballot(interior) == 0ull) break;
+            if (interior) {
+                const DevNode4& n = sc.nodes4[ref];
+                ctr.nodes++;
+                RT_PROBE(ctr, 2);
+                // all four boxes first (one batch of loads), then the choice of where to go
+                bool ok[4];
+                uint32_t rf[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float t0x = __builtin_fmaf(n.lo[0][c], ix, cx), t1x = __builtin_fmaf(n.hi[0][c], ix, cx);
+                    const float t0y = __builtin_fmaf(n.lo[1][c], iy, cy), t1y = __builtin_fmaf(n.hi[1][c], iy, cy);
+                    const float t0z = __builtin_fmaf(n.lo[2][c], iz, cz), t1z = __builtin_fmaf(n.hi[2][c], iz, cz);
+                    const float a = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)) - M;
+                    const float b = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) + M;
+                    rf[c] = n.child[c];
+                    ok[c] = rf[c] != RT_REF_END && a <= b && !(a > tl) && !(b < 0.0f);
+                }
+                uint32_t next = RT_REF_END;
+                bool have = false;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (ok[c]) {
+                        if (!have) next = rf[c], have = true;
+                        else if (sp < RT_STACK) stk[sp * 64] = rf[c], sp++;
+                    }
+                }
+                ref = have ? next : (sp > 0 ? stk[(--sp) * 64] : RT_REF_END);
+            }
+        }
+        // ---- one triangle for the lanes that stand at a leaf ----
+        if (ref != RT_REF_END && (ref & RT_REF_LEAF)) {
+            const uint32_t leaf_index = ref & ~RT_REF_LEAF;
+            const rt_bvh_leaf& lf = sc.leaves[leaf_index];
+            ctr.tris++;
+            RT_PROBE(ctr, 3);
+            ref = sp > 0 ? stk[(--sp) * 64] : RT_REF_END;
+            const d3 O1 = D3(lf.O1), O2 = D3(lf.O2), O3 = D3(lf.O3), e1 = O2 - O1, e2 = O3 - O1;
+            bool hit = false;
+            d3 p = cross(d, e2);
+            double det = dot(e1, p);
+            if (!(fabs(det) < RT_EPS)) {
+                double idet = 1.0 / det;
+                d3 tv = o - O1;
+                double u = dot(tv, p) * idet;
+                if (!(u < 0.0 || u > 1.0)) {
+                    d3 q = cross(tv, e1);
+                    double v = dot(d, q) * idet;
+                    if (!(v < 0.0 || u + v > 1.0)) {
+                        double t0 = dot(e2, q) * idet;
+                        if (!(t0 <= RT_EPS) && t_limit - t0 > RT_EPS) {
+                            // the reference must have reached this leaf (see mesh_walk4)
+                            const d3 P = o + d * t0;
+                            const double eps = 1e-9 * (S + fabs(o.x) + fabs(o.y) + fabs(o.z) + fabs(P.x) + fabs(P.y) + fabs(P.z));
+                            const bool inside = P.x - fmin(O1.x, fmin(O2.x, O3.x)) > eps && fmax(O1.x, fmax(O2.x, O3.x)) - P.x > eps &&
+                                                P.y - fmin(O1.y, fmin(O2.y, O3.y)) > eps && fmax(O1.y, fmax(O2.y, O3.y)) - P.y > eps &&
+                                                P.z - fmin(O1.z, fmin(O2.z, O3.z)) > eps && fmax(O1.z, fmax(O2.z, O3.z)) - P.z > eps;
+                            hit = inside || reference_reaches_leaf(sc, leaf_index, o, D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z));
+                        }
+                    }
+                }
+            }
+            if (hit) {
+                flag[ray] = 1u;
+                ref = RT_REF_END, sp = 0;
+            }
+        }
+    }
+    return enter && flag[lane] != 0u;
+}
+
 // CR/Collision_Mesh.cu:45-60: hit record of the winning leaf (normal as CR/primitive.cpp:457 stores it)
 DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double t0, Hit& h) {
     const rt_bvh_leaf& lf = sc.leaves[leafref & ~RT_REF_LEAF];
@@ -1019,6 +1164,72 @@ DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int c
         if (dist - t > RT_EPS) return false;
     }
     return true;
+}
+
+// shadow_clear for the pruned mode, called by all 64 lanes (`act` = this lane has a ray): the meshes are walked with
+// mesh_anyhit_shared, so lanes without a ray, or whose ray is already known to be occluded, help the others.
+DEV bool shadow_clear_shared(const DevScene& sc, uint32_t flags, bool act, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
+                             Counters& ctr, uint32_t* stk, uint32_t* xch) {
+    const d3 Vv = target - C;
+    const double dist = module(Vv);
+    const d3 V = Vv / dist;  // = normalize(Vv)
+    const d3 dm = (flags & RT_F_MESH_RAW_DIR) ? Vv : V;
+    uint32_t dummy_n = 0;
+    const bool self_skip = (flags & RT_F_SHADOW_SELF_SKIP) != 0;
+    bool alive = act;  // has a ray that nothing has occluded so far
+    int sp = 0;        // roots of the meshes the ray may enter, on this lane's stack
+    for (int j = 0; j < sc.n_prims; j++) {
+        const bool mine = alive && (j >= 64 || ((cand >> j) & 1ull)) && !(self_skip && j == crashed) && j != light_prim;
+        if (__ballot(mine) == 0ull) continue;
+        if (!mine) continue;
+        const DevGeom RT_CONST& g = GEOM(sc)[j];
+        Hit tmp;
+        double t = RT_BIG_DIST;
+        switch (g.type) {
+            case RT_PRIM_SPHERE: t = sphere_hit<false>(g, C, V, tmp); break;
+            case RT_PRIM_PLANE: t = plane_hit<false>(g, C, V, tmp); break;
+            case RT_PRIM_SQUARE: t = square_hit<false>(g, C, V, tmp); break;
+            case RT_PRIM_CYLINDER:
+                if (ball_may_hit(g, C, V, dist)) t = cylinder_hit<false>(g, C, V, tmp);
+                break;
+            case RT_PRIM_BEZIER:
+                if (!(flags & RT_F_BEZIER_STACKED)) {
+                    if (ball_may_hit(g, C, V, dist)) t = bezier_newton_hit<false>(sc, g, C, V, tmp);
+                } else if (ball_may_hit(g, C, V, RT_BIG_DIST)) {
+                    t = bezier_stacked_hit<false>(sc, g, C, V, RT_BIG_DIST, tmp);
+                }
+                break;
+            case RT_PRIM_TRIANGLE: t = triangle_hit<false>(g, C, dm, tmp); break;
+            case RT_PRIM_MESH: {
+                // the root box test of mesh_walk4; rays whose slab distances do not fit single precision walk on their own
+                const d3 inv = D3(1.0 / dm.x, 1.0 / dm.y, 1.0 / dm.z);
+                const double S = g.f[MSH_SCALE];
+                const double mm = fmax(fmax((S + fabs(C.x)) * fabs(inv.x), (S + fabs(C.y)) * fabs(inv.y)), (S + fabs(C.z)) * fabs(inv.z));
+                if (!g.aux2 || sp >= RT_STACK / 4 || !(mm < 1e30) || !(fabs(inv.x) < 1e30) || !(fabs(inv.y) < 1e30) || !(fabs(inv.z) < 1e30)) {
+                    // (also: a mesh without a four-wide tree, a ray with more candidate meshes than roots are kept for)
+                    t = mesh_walk<false, true, false>(sc, g.aux0, C, dm, dist, S, ctr, nullptr, 0, dummy_n, 0).t;
+                } else {
+                    ctr.nodes++;
+                    const double margin = 1e-13 * mm;
+                    double t0x = (g.f[MSH_BMIN] - C.x) * inv.x, t1x = (g.f[MSH_BMAX] - C.x) * inv.x;
+                    double t0y = (g.f[MSH_BMIN + 1] - C.y) * inv.y, t1y = (g.f[MSH_BMAX + 1] - C.y) * inv.y;
+                    double t0z = (g.f[MSH_BMIN + 2] - C.z) * inv.z, t1z = (g.f[MSH_BMAX + 2] - C.z) * inv.z;
+                    double tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
+                    double tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
+                    if (!(!(tn <= tf) || tn > dist + margin + 1e-9 * fabs(dist) || tf < -margin)) stk[sp * 64] = (uint32_t)(g.aux2 - 1), sp++;
+                }
+                break;
+            }
+            default: break;
+        }
+        if (dist - t > RT_EPS) alive = false;
+    }
+    // all meshes in one walk, shared by the wave (every lane gets here: no lane leaves the loop above early)
+    if (!alive) sp = 0;
+    RT_LAP(ctr, PF_SH_PRIMS);
+    const bool occluded = mesh_anyhit_shared(sc, sc.mesh_scale_max, sp, C, dm, dist, ctr, stk, xch);
+    RT_LAP(ctr, PF_SH_MESH);
+    return alive && !occluded;
 }
 
 // ---- textures: CR/bmp.cpp:133-150 (double taps), CR/Primitive.cu:85-115 (8-bit taps) --------

@@ -30,6 +30,13 @@ class DeviceScene:
     def tree_build_ms(self):
         return float(self._lib.rt_scene_tree_build_ms(self._h))
 
+    @property
+    def shared_walk(self):
+        """(choice, plain_ms, shared_ms) of the shadow-walk variant: choice -1 = not made yet, 0 = plain, 1 = shared."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        choice = int(self._lib.rt_scene_shared_walk(self._h, C.byref(a), C.byref(b)))
+        return choice, a.value, b.value
+
     def close(self):
         if self._h:
             self._lib.rt_scene_destroy(self._h)

@@ -239,6 +239,13 @@ int rt_set_stream(void* hip_stream);
 int rt_set_tree_builder(int which);
 /* Device time of the last scene's tree build in ms (0 when the host built the trees). */
 double rt_scene_tree_build_ms(const rt_scene* scene);
+/* The render kernel exists in two variants that differ in how shadow rays walk the meshes (each ray on
+ * its own lane, or long walks shared out over idle lanes); they give the same image.  A scene gets the
+ * faster one: the first large pruned render times both on two equal samples of the frame's blocks.
+ * Returns the choice (-1 = not made yet, 0 = plain, 1 = shared) and the two sample times in ms (0 if no
+ * timing took place).  RT_AMD_SHARED_WALK=0|1 in the environment fixes the choice.  No counterpart in
+ * the reference. */
+int rt_scene_shared_walk(const rt_scene* scene, double* plain_ms, double* shared_ms);
 
 /* Upload a scene: one slab, one copy.  Replaces createCudaSceneFromCPUScene
  * (CR/Renderer_CUDA.cpp:298-335). */

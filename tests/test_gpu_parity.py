@@ -200,6 +200,32 @@ def test_trees_built_on_the_device_give_the_same_image(name, W, H, spp):
         assert np.array_equal(a, b)
 
 
+def test_shadow_walk_variants_give_the_same_image(monkeypatch):
+    """Plain and wave-shared shadow mesh walks, and the timed choice between them, render the same bits."""
+    hs = scene("c5_final")
+    W, H = 400, 264  # 1650 blocks: enough for the timing samples
+    st = orc.settings(spp=2, dof=True, focal=168.0, aperture=150.0, seed=5, flags=abi.RT_MODE_GPU_REF)
+    images, rays = [], []
+    for choice in ("0", "1", None):
+        if choice is None:
+            monkeypatch.delenv("RT_AMD_SHARED_WALK", raising=False)
+        else:
+            monkeypatch.setenv("RT_AMD_SHARED_WALK", choice)
+        with device_scene(hs) as ds:
+            img, s = ds.render_frame(st, W, H)
+            picked, plain_ms, shared_ms = ds.shared_walk
+            if choice is None:
+                assert picked in (0, 1) and plain_ms > 0.0 and shared_ms > 0.0
+                again, _ = ds.render_frame(st, W, H)
+                assert np.array_equal(again, img)
+            else:
+                assert picked == int(choice)
+        images.append(img)
+        rays.append(s.rays)
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
+    assert rays[0] == rays[1] == rays[2]
+
+
 FLAGS = [abi.RT_F_NORMALIZE_PRIMARY, abi.RT_F_SKY_Y, abi.RT_F_TIE_LATER_WINS, abi.RT_F_SHADOW_SELF_SKIP, abi.RT_F_SQUARE_UV_NO_ORIGIN,
          abi.RT_F_TEX_U8_TAPS, abi.RT_F_PIXEL_MAP_TRUNC, abi.RT_F_MESH_RAW_DIR]
 
