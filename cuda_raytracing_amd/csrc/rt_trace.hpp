@@ -709,10 +709,10 @@ DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d
 // Must be called by all lanes of the wave that are active at the call site; `want` = this lane has a ray to test.
 // `xch` = 3 * 64 words of LDS of this wave: flags, and two exchange arrays.
 #ifndef RT_STEAL_MIN
-#define RT_STEAL_MIN 16  // idle lanes that make a round of hand-overs worth its cost
+#define RT_STEAL_MIN 8  // idle lanes that make a round of hand-overs worth its cost (c5_final ms/frame: 4: 201, 8: 201, 12: 205, 16: 211)
 #endif
 #ifndef RT_SHARE_STEPS
-#define RT_SHARE_STEPS 4  // interior steps between two looks at who is idle
+#define RT_SHARE_STEPS 2  // interior steps between two looks at who is idle (1: 207, 2: 201, 4: 211)
 #endif
 // On entry the lane's stack (sp entries) holds the roots of the meshes its ray may enter; `S` = the largest mesh scale
 // of the scene (it only widens the error bounds).  The ray is passed by value and overwritten by hand-overs.
