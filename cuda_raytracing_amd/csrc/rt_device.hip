@@ -73,6 +73,10 @@ struct RenderParams {
 #ifndef RT_LAUNCH_PATHS
 #define RT_LAUNCH_PATHS (1ull << 28)  // most paths of one launch (their colours take 24 bytes each: 6.4 GB); larger calls are cut into several launches
 #endif
+#ifndef RT_SHARE_CLOSEST
+#define RT_SHARE_CLOSEST 0  // 1: the shared variant also shares its closest-hit walks (mesh_closest_shared).  Halves the steps of those
+                           // walks, but what it costs in registers around them is as much: c4_lucy 43.7 -> 44.8, c5_final 201 -> 197 ms/frame
+#endif
 #ifndef RT_TUNE_BLOCKS
 #define RT_TUNE_BLOCKS 1024  // blocks per variant in the timing sample that picks the shadow-walk variant (2 M paths at 32 spp)
 #endif
@@ -367,7 +371,7 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
 #endif
         if (tracing && sp + 1 <= RT_MAX_DEPTH) {
             if (sp > 0) ctr.rays_secondary++;
-            h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log, stk);
+            h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log, stk, RT_SHARE_CLOSEST && SHARE ? xch : nullptr);
             if (h.prim < 0) {
                 d3 c = unit(d);
                 double t = 0.5 * (((P.flags & RT_F_SKY_Y) ? c.y : c.z) + 1.0);
@@ -524,9 +528,9 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     ctr.prof = s_prof[threadIdx.x >> 6];
     if (lane < 1 + PF_COUNT) ctr.prof[lane] = lane == 0 ? __builtin_readcyclecounter() : 0ull;
 #endif
-    // flags and exchange arrays of the shared any-hit walk, 3 * 64 words per wave
-    __shared__ uint32_t s_xch[SHARE ? 4 * 192 : 1];
-    uint32_t* xch = SHARE ? s_xch + (threadIdx.x >> 6) * 192 : nullptr;
+    // flags, exchange arrays and per-ray hit records of the shared walks, 448 words per wave
+    __shared__ __attribute__((aligned(8))) uint32_t s_xch[SHARE ? 4 * 448 : 2];
+    uint32_t* xch = SHARE ? s_xch + (threadIdx.x >> 6) * 448 : nullptr;
     trace_stream<STRICT, SHARE>(P, shade, ctr, stk, xch);
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_REFILL);

@@ -745,7 +745,8 @@ DEV bool mesh_anyhit_shared(const DevScene& sc, double S, int sp, d3 o, d3 d, do
         if (busy == 0ull) break;
         // ---- hand-overs: the k-th idle lane takes the top of the stack of the k-th lane that has one ----
         const unsigned long long givers = __ballot(ref != RT_REF_END && sp > 0);
-        const int n_idle = 64 - __popcll(busy), n_give = __popcll(givers);
+        const unsigned long long idlers = __ballot(ref == RT_REF_END);  // of the lanes that are here: some may not have been called
+        const int n_idle = __popcll(idlers), n_give = __popcll(givers);
         if (n_idle >= RT_STEAL_MIN && n_give > 0) {
             const bool giver = ref != RT_REF_END && sp > 0;
             if (giver) {
@@ -756,7 +757,7 @@ DEV bool mesh_anyhit_shared(const DevScene& sc, double S, int sp, d3 o, d3 d, do
                 }
             }
             const bool idle = ref == RT_REF_END;
-            const int k = rank_in(~busy);
+            const int k = rank_in(idlers);
             const bool take = idle && k < n_give;
             const int from = take ? (int)x_lane[k] : lane;
             // the ray, from the lane that gives
@@ -843,6 +844,179 @@ DEV bool mesh_anyhit_shared(const DevScene& sc, double S, int sp, d3 o, d3 d, do
     return enter && flag[lane] != 0u;
 }
 
+// ---- closest-hit walk shared by the wave ----------------------------------------------------------
+// The same hand-overs as mesh_anyhit_shared.  Every lane that works on a ray prunes with the ray's best distance so far,
+// kept in LDS, and an accepted triangle is written to the ray's record by one lane at a time (distance, then pre-order
+// index: the rule of mesh_walk4), so the record ends up holding what a single lane would have found.
+// Must be called by all lanes that are active at the call site.  `xch` = 448 words of LDS of this wave.
+DEV MeshResult mesh_closest_shared(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk,
+                                   uint32_t* xch) {
+    const int lane = lane_id();
+    uint32_t* x_lane = xch + 64;
+    uint32_t* x_ref = xch + 128;
+    double* rec_t = reinterpret_cast<double*>(xch + 192);
+    uint32_t* rec_pre = xch + 320;
+    uint32_t* rec_leaf = xch + 384;
+    const double S = g.f[MSH_SCALE];
+    MeshResult res{RT_BIG_DIST, RT_REF_END};
+    bool enter = true;
+    float ix, iy, iz, cx, cy, cz, M, tl;
+    {
+        const d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        const double mm = fmax(fmax((S + fabs(o.x)) * fabs(inv.x), (S + fabs(o.y)) * fabs(inv.y)), (S + fabs(o.z)) * fabs(inv.z));
+        if (!(mm < 1e30) || !(fabs(inv.x) < 1e30) || !(fabs(inv.y) < 1e30) || !(fabs(inv.z) < 1e30)) {
+            uint32_t dummy = 0;  // slab distances beyond single precision: this ray walks on its own, in double
+            res = mesh_walk<false, false, false>(sc, g.aux0, o, d, t_limit, S, ctr, nullptr, 0, dummy, 0);
+            enter = false;
+        } else {
+            ctr.nodes++;
+            const double margin = 1e-13 * mm;
+            double t0x = (g.f[MSH_BMIN] - o.x) * inv.x, t1x = (g.f[MSH_BMAX] - o.x) * inv.x;
+            double t0y = (g.f[MSH_BMIN + 1] - o.y) * inv.y, t1y = (g.f[MSH_BMAX + 1] - o.y) * inv.y;
+            double t0z = (g.f[MSH_BMIN + 2] - o.z) * inv.z, t1z = (g.f[MSH_BMAX + 2] - o.z) * inv.z;
+            double tn = fmax(fmax(fmin(t0x, t1x), fmin(t0y, t1y)), fmin(t0z, t1z));
+            double tf = fmin(fmin(fmax(t0x, t1x), fmax(t0y, t1y)), fmax(t0z, t1z));
+            if (!(tn <= tf) || tn > t_limit + margin + 1e-9 * fabs(t_limit) || tf < -margin) enter = false;
+        }
+        ix = (float)inv.x, iy = (float)inv.y, iz = (float)inv.z;
+        cx = (float)(-(o.x * inv.x)), cy = (float)(-(o.y * inv.y)), cz = (float)(-(o.z * inv.z));
+        M = (float)(mm * 2.4e-7) * 1.000001f + 1e-30f;
+        tl = (float)t_limit;
+        tl = tl + fabsf(tl) * 2.4e-7f;
+    }
+    if (__ballot(enter) == 0ull) return res;
+    rec_t[lane] = RT_BIG_DIST, rec_pre[lane] = 0xFFFFFFFFu, rec_leaf[lane] = RT_REF_END;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
+    uint32_t ref = enter ? (uint32_t)(g.aux2 - 1) : RT_REF_END;
+    int sp = 0;
+    int ray = lane;  // the lane whose ray this lane is working on
+    RT_PROBE(ctr, 1);
+    for (;;) {
+        if (ref != RT_REF_END) {  // prune with what anybody has found for this ray
+            const float best = (float)rec_t[ray];
+            tl = fminf(tl, best + fabsf(best) * 2.4e-7f);
+        }
+        const unsigned long long busy = __ballot(ref != RT_REF_END);
+        if (busy == 0ull) break;
+        // ---- hand-overs: the k-th idle lane takes the top of the stack of the k-th lane that has one ----
+        const unsigned long long givers = __ballot(ref != RT_REF_END && sp > 0);
+        const unsigned long long idlers = __ballot(ref == RT_REF_END);  // of the lanes that are here: some may not have been called
+        const int n_idle = __popcll(idlers), n_give = __popcll(givers);
+        if (n_idle >= RT_STEAL_MIN && n_give > 0) {
+            const bool giver = ref != RT_REF_END && sp > 0;
+            if (giver) {
+                const int k = rank_in(givers);
+                if (k < n_idle) {
+                    x_lane[k] = (uint32_t)lane;
+                    x_ref[k] = stk[(--sp) * 64];
+                }
+            }
+            const bool idle = ref == RT_REF_END;
+            const int k = rank_in(idlers);
+            const bool take = idle && k < n_give;
+            const int from = take ? (int)x_lane[k] : lane;
+            o = shfl_d3(o, from), d = shfl_d3(d, from);
+            ix = __shfl(ix, from, 64), iy = __shfl(iy, from, 64), iz = __shfl(iz, from, 64);
+            cx = __shfl(cx, from, 64), cy = __shfl(cy, from, 64), cz = __shfl(cz, from, 64);
+            M = __shfl(M, from, 64), tl = __shfl(tl, from, 64);
+            ray = __shfl(ray, from, 64);
+            if (take) ref = x_ref[k];
+        }
+        // the planes the ray enters through (lo where it runs up the axis, hi where it runs down) and leaves through
+        const uint32_t onx = (uint32_t)(__float_as_int(ix) >> 31) & 48u, ony = ((uint32_t)(__float_as_int(iy) >> 31) & 48u) + 16u,
+                       onz = ((uint32_t)(__float_as_int(iz) >> 31) & 48u) + 32u;
+        const uint32_t ofx = 48u - onx, ofy = 80u - ony, ofz = 112u - onz;
+        // ---- a few interior steps, nearest child first ----
+#pragma unroll 1
+        for (int step = 0; step < RT_SHARE_STEPS; step++) {
+            const bool interior = ref != RT_REF_END && !(ref & RT_REF_LEAF);
+            if (__ballot(interior) == 0ull) break;
+            if (interior) {
+                ctr.nodes++;
+                RT_PROBE(ctr, 4);
+                float key[4];
+                uint32_t rf[4];
+                const uint32_t nb = ref * (uint32_t)sizeof(DevNode4);
+                const f4 nx = *reinterpret_cast<const f4*>(nbase + (nb + onx)), ny = *reinterpret_cast<const f4*>(nbase + (nb + ony)),
+                         nz = *reinterpret_cast<const f4*>(nbase + (nb + onz));
+                const f4 fx = *reinterpret_cast<const f4*>(nbase + (nb + ofx)), fy = *reinterpret_cast<const f4*>(nbase + (nb + ofy)),
+                         fz = *reinterpret_cast<const f4*>(nbase + (nb + ofz));
+                const u4 ch = *reinterpret_cast<const u4*>(nbase + (nb + 96u));
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float a = fmaxf(fmaxf(__builtin_fmaf(nx[c], ix, cx), __builtin_fmaf(ny[c], iy, cy)), __builtin_fmaf(nz[c], iz, cz)) - M;
+                    const float b = fminf(fminf(__builtin_fmaf(fx[c], ix, cx), __builtin_fmaf(fy[c], iy, cy)), __builtin_fmaf(fz[c], iz, cz)) + M;
+                    rf[c] = ch[c];
+                    const bool ok = rf[c] != RT_REF_END && a <= b && !(a > tl) && !(b < 0.0f);
+                    key[c] = ok ? a : __builtin_inff();
+                }
+#define RT_CE(i, j)                                                  \
+    {                                                                \
+        const bool sw = key[j] < key[i];                             \
+        const float ka = sw ? key[j] : key[i], kb = sw ? key[i] : key[j]; \
+        const uint32_t ra = sw ? rf[j] : rf[i], rb = sw ? rf[i] : rf[j];  \
+        key[i] = ka, key[j] = kb, rf[i] = ra, rf[j] = rb;            \
+    }
+                RT_CE(0, 1) RT_CE(2, 3) RT_CE(0, 2) RT_CE(1, 3) RT_CE(1, 2)
+#undef RT_CE
+                if (key[3] < __builtin_inff() && sp < RT_STACK) stk[sp * 64] = rf[3], sp++;
+                if (key[2] < __builtin_inff() && sp < RT_STACK) stk[sp * 64] = rf[2], sp++;
+                if (key[1] < __builtin_inff() && sp < RT_STACK) stk[sp * 64] = rf[1], sp++;
+                if (key[0] < __builtin_inff()) ref = rf[0];
+                else ref = sp > 0 ? stk[(--sp) * 64] : RT_REF_END;
+            }
+        }
+        // ---- one triangle for the lanes that stand at a leaf ----
+        bool hit = false;
+        double hit_t = 0.0;
+        uint32_t hit_pre = 0, hit_ref = 0;
+        if (ref != RT_REF_END && (ref & RT_REF_LEAF)) {
+            const uint32_t here = ref, leaf_index = ref & ~RT_REF_LEAF;
+            const rt_bvh_leaf& lf = sc.leaves[leaf_index];
+            ctr.tris++;
+            RT_PROBE(ctr, 5);
+            ref = sp > 0 ? stk[(--sp) * 64] : RT_REF_END;
+            const d3 O1 = D3(lf.O1), O2 = D3(lf.O2), O3 = D3(lf.O3), e1 = O2 - O1, e2 = O3 - O1;
+            d3 p = cross(d, e2);
+            double det = dot(e1, p);
+            if (!(fabs(det) < RT_EPS)) {
+                double idet = 1.0 / det;
+                d3 tv = o - O1;
+                double u = dot(tv, p) * idet;
+                if (!(u < 0.0 || u > 1.0)) {
+                    d3 q = cross(tv, e1);
+                    double v = dot(d, q) * idet;
+                    if (!(v < 0.0 || u + v > 1.0)) {
+                        double t0 = dot(e2, q) * idet;
+                        const double cur = rec_t[ray];
+                        if (!(t0 <= RT_EPS) && (t0 < cur || (t0 == cur && lf.preorder < rec_pre[ray]))) {
+                            // the reference must have reached this leaf (see mesh_walk4)
+                            const d3 P = o + d * t0;
+                            const double eps = 1e-9 * (S + fabs(o.x) + fabs(o.y) + fabs(o.z) + fabs(P.x) + fabs(P.y) + fabs(P.z));
+                            const bool inside = P.x - fmin(O1.x, fmin(O2.x, O3.x)) > eps && fmax(O1.x, fmax(O2.x, O3.x)) - P.x > eps &&
+                                                P.y - fmin(O1.y, fmin(O2.y, O3.y)) > eps && fmax(O1.y, fmax(O2.y, O3.y)) - P.y > eps &&
+                                                P.z - fmin(O1.z, fmin(O2.z, O3.z)) > eps && fmax(O1.z, fmax(O2.z, O3.z)) - P.z > eps;
+                            hit = inside || reference_reaches_leaf(sc, leaf_index, o, D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z));
+                            hit_t = t0, hit_pre = lf.preorder, hit_ref = here;
+                        }
+                    }
+                }
+            }
+        }
+        // accepted triangles go to their rays' records one lane at a time: two lanes may have found one for the same ray
+        for (unsigned long long hm = __ballot(hit); hm != 0ull; hm &= hm - 1ull) {
+            if (lane == (int)__ffsll((long long)hm) - 1) {
+                const double cur = rec_t[ray];
+                if (hit_t < cur || (hit_t == cur && hit_pre < rec_pre[ray])) rec_t[ray] = hit_t, rec_pre[ray] = hit_pre, rec_leaf[ray] = hit_ref;
+            }
+        }
+    }
+    if (enter) res.t = rec_t[lane], res.leaf = rec_leaf[lane];
+    return res;
+}
+
 // CR/Collision_Mesh.cu:45-60: hit record of the winning leaf (normal as CR/primitive.cpp:457 stores it)
 DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double t0, Hit& h) {
     const rt_bvh_leaf& lf = sc.leaves[leafref & ~RT_REF_LEAF];
@@ -857,7 +1031,7 @@ DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double 
 // ---- closest hit over the scene: CR/Scene.cu:3-21, CR/Scene.cpp:27-38 ---------------------
 template <bool STRICT, bool LOG>
 DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint32_t* log, uint32_t log_cap,
-                      uint32_t& log_n, uint32_t* stk) {
+                      uint32_t& log_n, uint32_t* stk, uint32_t* xch = nullptr) {
     Hit best;
     best.prim = -1, best.leaf = -1, best.dist = RT_BIG_DIST, best.front = false;
     best.N = D3(0, 0, 0), best.C = D3(0, 0, 0);
@@ -896,7 +1070,9 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
             case RT_PRIM_TRIANGLE: t = triangle_hit<true>(g, o, dm, tmp); break;
             case RT_PRIM_MESH: {
                 RT_LAP(ctr, PF_CLOSEST_PRIMS);
-                MeshResult r = (!STRICT && g.aux2 && stk)
+                MeshResult r = (!STRICT && g.aux2 && stk && xch)
+                                   ? mesh_closest_shared(sc, g, o, dm, lim, ctr, stk, xch)
+                               : (!STRICT && g.aux2 && stk)
                                    ? mesh_walk4<false>(sc, g, o, dm, lim, ctr, stk)
                                    : mesh_walk<STRICT, false, LOG>(sc, g.aux0, o, dm, lim, g.f[MSH_SCALE], ctr, log, log_cap, log_n,
                                                                    (uint32_t)g.aux1 << 24);
