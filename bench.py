@@ -64,7 +64,7 @@ def cpu_baseline(hs, st, width, height, budget_s=25.0):
 
 
 def measured_traffic():
-    """HBM-side bytes of one render_kernel<false, 16> launch of this same command, from the rocprofv3 PMC passes
+    """HBM-side bytes of one render_kernel<false, 16, ...> launch of this same command, from the rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE, each in a process of its own) that tools/profile_round.sh summarised last."""
     path = os.path.join(ROOT, "profiles", "current", "pmc_render_kernel.json")
     try:
@@ -205,7 +205,7 @@ def main():
             touched = 128 * last.nodes_visited + 96 * last.tris_tested  # four-wide nodes and leaf records the pruned walk loaded
             traffic, tnote = measured_traffic()
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                               "traffic": traffic, "kernel": "render_kernel<false, 16>", "kernel_ms_avg": kavg,
+                               "traffic": traffic, "kernel": "render_kernel<false, 16, %s>" % ("true" if picked == 1 else "false"), "kernel_ms_avg": kavg,
                                "algorithmic_bytes_per_launch": ab,
                                "bvh_bytes_requested_per_launch": touched,
                                "strict_kernel_ms": strict_stats.kernel_ms,
@@ -218,7 +218,7 @@ def main():
                 out["roofline"].update(tnote)
         else:
             out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
-                               "kernel": "render_kernel<false, 16>", "kernel_ms_avg": kavg}
+                               "kernel": "render_kernel<false, 16, %s>" % ("true" if picked == 1 else "false"), "kernel_ms_avg": kavg}
         if world == 1 and not args.no_cpu_baseline:
             st.flags = abi.RT_MODE_GPU_REF
             out["cpu_baseline"] = cpu_baseline(hs, st, W, H)
