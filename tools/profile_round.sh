@@ -6,6 +6,8 @@ R=${1:-r01}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
+# the kernel variant is fixed so that every frame is one render launch (the timed choice would add four sample launches to the first frame)
+export RT_AMD_SHARED_WALK=${RT_AMD_SHARED_WALK:-1}
 B="python3 bench.py --no-cpu-baseline"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_fetch.log 2>&1
