@@ -988,7 +988,7 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
             }
             if (round == 0) HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));  // its rays are not the frame's
         }
-        s->shared_walk = ms[1] < 0.97f * ms[0] ? 1 : 0;  // the plain variant unless sharing is clearly faster
+        s->shared_walk = ms[1] < 0.99f * ms[0] ? 1 : 0;  // the plain variant unless sharing is faster by more than the timing noise
         s->tune_ms[0] = ms[0], s->tune_ms[1] = ms[1];
         done = 2 * sample;
     }
