@@ -1,19 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Lucy 34k-triangle scene, 1920x1080, 32 samples per pixel, depth of field on,
-rendered through the C ABI on N GPUs of one node (tiles interleaved over ranks, one gather).
+"""Benchmark of the render path through the C ABI, on N GPUs of one node.
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py [--config headline|c1|c2|c3|c4|c5] [--gpus N] [--steps K] [--warmup W]
 
-A step = one full frame (every rank renders its tiles into device memory, rank 0 gathers).  The
-scene is resident in HBM before the timed region; rank 0 prints one JSON line.  `value` is all rays
-of the frame (primary + reflect/refract + shadow, counted by the kernel) per second of the slowest
-rank.  `roofline` prices the render kernel of rank 0 with the algorithmic-bytes model
-64*nodes + 72*tris + 48/ray + 4/pixel + 128/shaded hit + 16/texture fetch, where nodes and tris are
-the visit counts of the reference-order (strict) traversal of the same tiles; `traffic` is read from the
-PMC summary under profiles/current/ (rocprofv3 cannot run inside this process).  `cpu_baseline` times
-the CPU oracle (a port of the reference algorithm, OpenMP) on a bounded sample of the same frame.
+--gpus N > 1 without a torch.distributed environment starts the N ranks itself (one process per GPU, before anything
+touches a GPU); it can also be launched as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one full frame of the configuration: every rank renders its tiles (tile t -> rank t % N) into device memory,
+rank 0 gathers them.  The scene is resident in HBM before the timed region; rank 0 prints one JSON line.
+
+What the line reports
+  value                    rays of the frame per second of the slowest rank, counting every ray the reference traces for
+                           this frame (primary + reflect/refract + one shadow ray per light sample per shaded point).
+                           Most shadow samples are decided here without a ray (lamp behind the surface, nothing that can
+                           stand in between, point inside an umbra - the image is bit-identical to tracing them all), so
+                           this is a rate of rays *resolved*;
+  mrays_per_s_traced       the same with only the shadow rays that were actually intersected with the scene;
+  mrays_per_s_primary_only pixels x samples per second, the one figure that can be derived for the reference's own timings;
+  roofline                 the render kernel against the roof that binds it: vector-ALU issue.  Its instruction mix is
+                           double-precision without fused multiply-add (bit parity with the reference forbids contraction),
+                           so the roof is one vector instruction per SIMD per 4 cycles; `achieved` = vector instructions of
+                           one launch (SQ_INSTS_VALU of the same command under rocprofv3, profiles/current/) x 64 lanes /
+                           the kernel time measured live with HIP events.  `flops_model` prices the same launch with the
+                           per-operation flop counts of the traversal (slab test 30, triangle test 60, ...) against the
+                           78.6 TFLOP/s FP64 vector peak; `hbm` puts the HBM counter traffic next to the bytes the kernel
+                           has to move (path colours + scene).
+  cpu_baseline             the CPU oracle (a port of the reference algorithm, OpenMP, every ray traced in reference order)
+                           on a bounded sample of the same frame; for c1 also the reference's own CPU renderer.
 """
 import argparse
 import json
@@ -25,12 +39,52 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec)
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E
+FP64_VECTOR_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz
+SIMDS = 1024
+CLOCK_GHZ = 2.4
+VALU_LANE_OPS_PEAK = SIMDS * 16 * CLOCK_GHZ / 1e3  # 39.3 T lane-instructions/s: one 64-lane instruction per SIMD per 4 cycles
+
+# name -> (scene, width, height, spp, dof, aperture, focal, semantics preset): BASELINE.json:configs, CR/main.cpp:5-16
+CONFIGS = {
+    "c1": ("c1_purple_sphere", 640, 480, 1, False, 10.0, 10.0, "cpu_ref"),
+    "c2": ("c2_textured_mirror", 1280, 720, 128, True, 10.0, 10.2, "gpu_ref"),
+    "c3": ("c3_orange", 1920, 1080, 64, True, 10.0, 14.5, "gpu_ref"),
+    "headline": ("c4_lucy", 1920, 1080, 32, True, 1.0, 1.35, "gpu_ref"),
+    "c4": ("c4_lucy", 3840, 2160, 32, True, 1.0, 1.35, "gpu_ref"),
+    "c5": ("c5_final", 1920, 1080, 128, True, 150.0, 168.0, "gpu_ref"),
+}
 
 
-def algorithmic_bytes(s):
-    return (64 * s.nodes_visited + 72 * s.tris_tested + 48 * (s.rays_primary + s.rays_secondary + s.rays_shadow)
-            + 4 * s.pixels + 128 * s.shaded_hits + 16 * s.texture_fetches)
+def describe(hs, abi):
+    """Workload string from the scene itself."""
+    d = hs.desc
+    names = {abi.RT_PRIM_SPHERE: "sphere", abi.RT_PRIM_PLANE: "plane", abi.RT_PRIM_SQUARE: "square", abi.RT_PRIM_CYLINDER: "cylinder",
+             abi.RT_PRIM_BEZIER: "Bezier", abi.RT_PRIM_TRIANGLE: "triangle", abi.RT_PRIM_MESH: "mesh"}
+    counts = {}
+    for i in range(d.n_primitives):
+        if d.primitives[i].is_light:
+            continue
+        n = names[d.primitives[i].type]
+        counts[n] = counts.get(n, 0) + 1
+    lamps = {}
+    for i in range(d.n_lights):
+        n = {abi.RT_LIGHT_POINT: "point", abi.RT_LIGHT_SQUARE: "square", abi.RT_LIGHT_SPHERE: "sphere"}[d.lights[i].type]
+        lamps[n] = lamps.get(n, 0) + 1
+    prims = ", ".join(f"{v} {k}{'s' if v > 1 and not k.endswith('s') else ''}" for k, v in sorted(counts.items()))
+    lights = ", ".join(f"{v} {k} lamp{'s' if v > 1 else ''}" for k, v in sorted(lamps.items()))
+    tris = f" ({d.n_leaves} triangles)" if d.n_leaves else ""
+    return f"{prims}{tris}; {lights}"
+
+
+def flops_model(s):
+    """Double-precision operations the launch performs, from its own counters: per four-wide node visited 4 slab tests
+    of 30 flop (SURVEY's per-test figure; they run in single precision here), 60 per triangle test, 40 per analytic
+    primitive test (every ray meets every top-level primitive of the scene), 50 per shaded hit and light, 25 per texture
+    fetch.  A model, not a measurement: it prices useful arithmetic, the instruction count prices everything."""
+    rays = s["rays_traced"]
+    return (120.0 * s["nodes_visited"] + 60.0 * s["tris_tested"] + 40.0 * rays * s["n_prims"] + 50.0 * s["shaded_hits"] * max(1, s["n_lights"])
+            + 25.0 * s["texture_fetches"])
 
 
 def cpu_baseline(hs, st, width, height, budget_s=25.0):
@@ -40,8 +94,10 @@ def cpu_baseline(hs, st, width, height, budget_s=25.0):
 
     lib = orc.load()
     cores = lib.orc_max_threads()
-    nx, ny, b = 16, 12, 32
-    rects = [(int((i + 0.5) * width / nx) - b // 2, int((j + 0.5) * height / ny) - b // 2, b, b) for j in range(ny) for i in range(nx)]
+    b = 32 if min(width, height) >= 256 else 16
+    nx, ny = 16, 12
+    rects = [(min(max(int((i + 0.5) * width / nx) - b // 2, 0), width - b), min(max(int((j + 0.5) * height / ny) - b // 2, 0), height - b), b, b)
+             for j in range(ny) for i in range(nx)]
     # blocks in an order that covers the frame evenly however early the budget ends: every 8th, then every 4th, ...
     order, seen = [], set()
     for stride in (8, 4, 2, 1):
@@ -60,34 +116,21 @@ def cpu_baseline(hs, st, width, height, budget_s=25.0):
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": int(cores), "kind": "port",
             "sample": f"{done} blocks of {b}x{b} pixels spread evenly over the same {width}x{height}x{st.spp}spp frame "
-                      f"({rays} rays in {dt:.1f} s, reference-order traversal, OpenMP over rows)"}
+                      f"({rays} rays in {dt:.1f} s; every ray traced, reference-order traversal, OpenMP over rows)"}
 
 
-def measured_traffic():
-    """HBM-side bytes of one render_kernel<false, 16, ...> launch of this same command, from the rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE, each in a process of its own) that tools/profile_round.sh summarised last."""
-    path = os.path.join(ROOT, "profiles", "current", "pmc_render_kernel.json")
+def profile_counters(config):
+    """Counters of one render-kernel launch of this configuration (one frame), from the rocprofv3 PMC passes of the same
+    command that tools/profile_round.sh summarised under profiles/current/ (rocprofv3 cannot run inside this process)."""
+    path = os.path.join(ROOT, "profiles", "current", f"pmc_{config}.json")
     try:
         with open(path) as f:
-            j = json.load(f)
-        fetch_kib, write_kib = j["pmc_fetch"]["FETCH_SIZE"], j["pmc_write"]["WRITE_SIZE"]
+            return json.load(f), os.path.relpath(path, ROOT)
     except Exception:
         return None, None
-    note = ("FETCH_SIZE + WRITE_SIZE (KiB -> bytes) of one launch, profiles/current/. FETCH_SIZE is taken as reported: the reads are "
-            "4-byte-per-lane scratch reloads and 16-byte-per-lane gathers, widths for which the gfx950 half-count of wide streaming "
-            "reads is not calibrated; at most 2x the fetch part. Nearly all of it is register-spill scratch and the path colours handed to the resolve kernel (3.2 GB), not scene data.")
-    extra = {}
-    try:
-        sq = j["pmc_sq"]
-        extra = {"valu_busy": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * (sq["SQ_WAVES"] / (256 * 4)),
-                 "wave_wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], "valu_insts": sq["SQ_INSTS_VALU"],
-                 "waves_per_simd": sq["SQ_WAVES"] / (256 * 4), "max_waves_per_simd": 8}
-    except Exception:
-        pass
-    return (fetch_kib + write_kib) * 1024.0, {"traffic_note": note, **extra}
 
 
-def reference_c1(lib_dir):
+def reference_c1():
     """The reference's own CPU renderer (oracle/_ref/ref_dump, both passes of Raytracer::Run) on config 1."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
     if not os.path.exists(exe):
@@ -96,7 +139,7 @@ def reference_c1(lib_dir):
         p = subprocess.run([exe, "run", os.path.join(ROOT, "scenes", "c1_purple_sphere.txt"), "/tmp/_c1_ref.bmp"], cwd=os.path.join(ROOT, "assets"),
                            capture_output=True, text=True, timeout=120)
         line = [l for l in p.stderr.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)["seconds"]
+        return json.loads(line)
     except Exception:
         return None
 
@@ -106,14 +149,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="c4_lucy")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=32)
+    ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
+    ap.add_argument("--scene", default=None, help="override the configuration's scene")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-strict", action="store_true", help="skip the reference-order pass that prices the roofline")
+    ap.add_argument("--no-strict", action="store_true", help="skip the reference-order pass (headline only) that counts the reference's node visits")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks ourselves; nothing in this process has touched a GPU yet (torch is not even imported)
+        from cuda_raytracing_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks(__file__, args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -126,15 +175,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    W, H = args.width, args.height
-    hs = HostScene(os.path.join(SCENE_DIR, args.scene + ".txt"))
-    st = abi.Settings(dof_enabled=1, spp=args.spp, focal_distance=1.35, aperture=1.0, seed=1, flags=abi.RT_MODE_GPU_REF)
+    scene_name, W, H, spp, dof, aperture, focal, preset = CONFIGS[args.config]
+    scene_name, W, H, spp = args.scene or scene_name, args.width or W, args.height or H, args.spp or spp
+    flags = abi.RT_MODE_GPU_REF if preset == "gpu_ref" else abi.RT_MODE_CPU_REF
+    hs = HostScene(os.path.join(SCENE_DIR, scene_name + ".txt"))
+    st = abi.Settings(dof_enabled=int(dof), spp=spp, focal_distance=focal, aperture=aperture, seed=1, flags=flags)
     ds = DeviceScene(hs, device=local)
     stream = torch.cuda.current_stream()
     ds.set_stream(stream.cuda_stream)
@@ -152,12 +202,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # reference-order traversal of this rank's tiles: the visit counts behind the algorithmic bytes
+    # reference-order traversal of this rank's tiles: how many nodes / triangles the reference's walk visits for the same frame
     strict_stats = None
-    if rank == 0 and not args.no_strict:
-        st.flags = abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL
+    if rank == 0 and args.config == "headline" and not args.no_strict:
+        st.flags = flags | abi.RT_F_STRICT_TRAVERSAL
         _, strict_stats = ds.render_frame(st, W, H, tile=args.tile, part=rank, n_parts=world, out=image)
-        st.flags = abi.RT_MODE_GPU_REF
+        st.flags = flags
 
     for _ in range(args.warmup):
         step()
@@ -170,61 +220,88 @@ def main():
         kernel_ms += last.kernel_ms
     sync()
     elapsed = time.perf_counter() - t0
-    rays = torch.tensor([float(last.rays), float(last.rays_primary)], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([float(last.rays), float(last.rays_primary), float(last.rays_traced)], dtype=torch.float64, device="cuda")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    frame_rays, frame_primary = float(rays[0].item()), float(rays[1].item())
+    frame_rays, frame_primary, frame_traced = (float(x) for x in rays.tolist())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        dof_txt = f"depth of field on (aperture {aperture:g}, focal {focal:g})" if dof else "depth of field off"
+        mesh_txt = "Lucy 34k-tri " if scene_name == "c4_lucy" else ""
         out = {
-            "metric": "Mrays/s (primary + reflect/refract + shadow rays), Lucy 34k-tri 1920x1080 32spp",
+            "metric": f"Mrays/s (primary + reflect/refract + shadow rays the reference traces for the frame), {mesh_txt}{scene_name} {W}x{H} {spp}spp",
             "value": frame_rays * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "seconds_per_frame": ms_per_step / 1e3,
+            "mrays_per_s_traced": frame_traced * args.steps / elapsed / 1e6,
             "mrays_per_s_primary_only": frame_primary * args.steps / elapsed / 1e6,
-            "rays_per_frame": frame_rays,
+            "rays_resolved_per_frame": frame_rays,
+            "rays_traced_per_frame": frame_traced,
+            "value_counts": "rays resolved: every shadow sample the reference traces counts, whether a ray was needed here or the sample was "
+                            "decided without one (same image bit for bit); mrays_per_s_traced counts only rays intersected with the scene",
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.scene}: Lucy 33,446-triangle mesh + 4 spheres, plane, cylinder, Bezier vase, 2 sphere lamps; "
-                                   f"{W}x{H}, {args.spp} spp, depth of field on (aperture 1, focal 1.35), semantics preset gpu_ref, pruned traversal",
+            "config": {"workload": f"{args.config}: {scene_name} ({describe(hs, abi)}); {W}x{H}, {spp} spp, {dof_txt}, semantics preset {preset}, pruned traversal",
                        "tile": args.tile, "partition": f"tile t -> rank t % {world}, gather to rank 0"},
         }
-        picked, plain_ms, shared_ms = ds.shared_walk
-        out["config"]["shadow_walk_variant"] = {"picked": {0: "plain", 1: "shared"}.get(picked, "plain (not timed)"),
-                                                "sample_ms_plain": plain_ms, "sample_ms_shared": shared_ms}
+        picked, _, _ = ds.shared_walk
+        n_prims = hs.desc.n_primitives
+        cap = 16 if n_prims <= 16 else 64 if n_prims <= 64 else 0
+        kname = "render_kernel<false, %d, %s>" % (cap, "true" if picked == 1 else "false")
+        out["config"]["shadow_walk_variant"] = {0: "plain", 1: "shared"}[picked]
         kavg = kernel_ms / args.steps
+        pmc, pmc_path = profile_counters(args.config)
+        counters = {"rays_traced": last.rays_traced, "nodes_visited": last.nodes_visited, "tris_tested": last.tris_tested, "shaded_hits": last.shaded_hits,
+                    "texture_fetches": last.texture_fetches, "n_prims": n_prims, "n_lights": hs.desc.n_lights}
+        flops = flops_model(counters)
+        needed = 24.0 * last.rays_primary * 2 + 4.0 * last.pixels + 7.0e6  # path colours written, then read by the resolve kernel; the frame; the scene once
+        roof = {"bound": "valu_issue", "unit": "T lane-instr/s", "peak": VALU_LANE_OPS_PEAK, "achieved": None, "frac": None, "traffic": None,
+                "kernel": kname, "kernel_ms_avg": kavg, "launches_per_frame": 1,
+                "peak_note": f"{SIMDS} SIMDs x 16 lanes x {CLOCK_GHZ} GHz: one 64-lane vector instruction per SIMD per 4 cycles (FP64 at full rate; "
+                             f"no FMA contraction, so the {FP64_VECTOR_TFLOPS} TFLOP/s FMA figure is out of reach by construction)",
+                "flops_model": {"flops_per_launch": flops, "achieved_tflops": flops / (kavg * 1e-3) / 1e12, "peak_tflops": FP64_VECTOR_TFLOPS,
+                                "frac": flops / (kavg * 1e-3) / 1e12 / FP64_VECTOR_TFLOPS},
+                "hbm": {"bytes_needed_per_launch": needed, "peak_gbps": HBM_PEAK_GBPS}}
+        if world == 1 and pmc:
+            try:
+                sq = pmc["pmc_sq"]
+                valu = sq["SQ_INSTS_VALU"]
+                roof["achieved"] = valu * 64 / (kavg * 1e-3) / 1e12
+                roof["frac"] = roof["achieved"] / VALU_LANE_OPS_PEAK
+                roof["valu_insts_per_launch"] = valu
+                roof["waves_per_simd"] = sq["SQ_WAVES"] / SIMDS
+                roof["wave_wait_frac"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+                roof["counters_from"] = pmc_path
+            except Exception:
+                pass
+            try:
+                traffic = (pmc["pmc_fetch"]["FETCH_SIZE"] + pmc["pmc_write"]["WRITE_SIZE"]) * 1024.0
+                roof["traffic"] = traffic
+                roof["hbm"].update({"traffic_bytes_per_launch": traffic, "achieved_gbps": traffic / (kavg * 1e-3) / 1e9,
+                                    "hbm_traffic_frac": traffic / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic_over_needed": traffic / needed,
+                                    "note": "FETCH_SIZE + WRITE_SIZE (KiB -> bytes) of one launch, FETCH_SIZE as reported (reads here are 4- to 16-byte "
+                                            "per-lane gathers and scratch reloads; wide streaming reads would be under-counted up to 2x on gfx950)"})
+            except Exception:
+                pass
         if strict_stats is not None:
-            ab = algorithmic_bytes(strict_stats)
-            achieved = ab / (kavg * 1e-3) / 1e9
-            touched = 128 * last.nodes_visited + 96 * last.tris_tested  # four-wide nodes and leaf records the pruned walk loaded
-            traffic, tnote = measured_traffic()
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                               "traffic": traffic, "kernel": "render_kernel<false, 16, %s>" % ("true" if picked == 1 else "false"), "kernel_ms_avg": kavg,
-                               "algorithmic_bytes_per_launch": ab,
-                               "bvh_bytes_requested_per_launch": touched,
-                               "strict_kernel_ms": strict_stats.kernel_ms,
-                               "strict_achieved": ab / (strict_stats.kernel_ms * 1e-3) / 1e9,
-                               "note": "achieved = algorithmic bytes of the reference-order traversal / pruned kernel time (rank 0's launch). "
-                                       "The pruned walk visits a small fraction of those nodes and the scene (a few MB) stays in L2, so the "
-                                       "figure exceeds the HBM peak: the kernel is bound by double-precision VALU issue and dependent-load "
-                                       "latency, not by HBM (see valu_busy / wave_wait_frac)"}
-            if tnote:
-                out["roofline"].update(tnote)
-        else:
-            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
-                               "kernel": "render_kernel<false, 16, %s>" % ("true" if picked == 1 else "false"), "kernel_ms_avg": kavg}
+            roof["reference_order_pass"] = {"kernel_ms": strict_stats.kernel_ms, "nodes_visited": strict_stats.nodes_visited,
+                                            "tris_tested": strict_stats.tris_tested,
+                                            "note": "the same frame with the reference's own traversal (every ray traced, no culling): what the pruned kernel avoids"}
+        out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            st.flags = abi.RT_MODE_GPU_REF
-            out["cpu_baseline"] = cpu_baseline(hs, st, W, H)
-            ref_s = reference_c1(ROOT)
-            if ref_s is not None:
-                out["cpu_baseline"]["reference_cpu_renderer_config1_seconds"] = ref_s
+            out["cpu_baseline"] = cpu_baseline(hs, st, W, H, budget_s=25.0 if args.config != "c1" else 5.0)
+            if args.config == "c1":
+                ref = reference_c1()
+                if ref is not None:
+                    out["cpu_baseline"]["reference_cpu_renderer"] = {"seconds_per_frame": ref["seconds"], "kind": "reference",
+                                                                      "what": "oracle/_ref/ref_dump: the reference's own CPU sources, Raytracer::Run (both passes) on this scene, all host cores",
+                                                                      "gpu_seconds_per_frame": ms_per_step / 1e3}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -132,14 +132,21 @@ class Settings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("shaded_hits", C.c_uint64),
-                ("texture_fetches", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("texture_fetches", C.c_uint64), ("pixels", C.c_uint64), ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("rays_shadow_traced", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
     @property
     def rays(self):
+        """Rays the reference traces for this work: every shadow sample counts, traced here or decided without a ray."""
         return self.rays_primary + self.rays_secondary + self.rays_shadow
+
+    @property
+    def rays_traced(self):
+        """Rays that were actually intersected with the scene."""
+        return self.rays_primary + self.rays_secondary + self.rays_shadow_traced
 
 
 # sizes the C side static_asserts as well
@@ -163,6 +170,15 @@ _SIGNATURES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render_tile": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p, _P(Stats)]),
     "rt_render_frame": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 7 + [C.c_void_p, _P(Stats)]),
+    "rt_device_count": (C.c_int, []),
+    "rt_scene_group_create": (C.c_int, [_P(SceneDesc), C.c_int, _P(C.c_int), _P(C.c_void_p)]),
+    "rt_scene_group_destroy": (None, [C.c_void_p]),
+    "rt_scene_group_size": (C.c_int, [C.c_void_p]),
+    "rt_scene_group_member_ms": (C.c_double, [C.c_void_p, C.c_int]),
+    "rt_render_frame_multi": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 5 + [C.c_void_p, _P(Stats)]),
+    "rt_member_pixels": (C.c_longlong, [C.c_int] * 5),
+    "rt_pack_tiles": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "rt_unpack_tiles": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "rt_trace_primary": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p] * 5 + [C.c_int]),
     "rt_last_error": (C.c_char_p, []),
 }

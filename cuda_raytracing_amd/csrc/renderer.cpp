@@ -7,8 +7,8 @@ static void check(int rc, const char* what) {
     if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + rt_last_error());
 }
 
-Renderer::Renderer(int w, int h, int tw, int th, const std::string& scene, const std::string& assets, int device)
-    : width(w), height(h), texture_width(tw), texture_height(th), assetDir(assets), device_(device) {
+Renderer::Renderer(int w, int h, int tw, int th, const std::string& scene, const std::string& assets, int device, int gpus)
+    : width(w), height(h), texture_width(tw), texture_height(th), assetDir(assets), device_(device), gpus_(gpus < 1 ? 1 : gpus) {
     settings.resampling_size = 1;  // defaults of CR/Renderer.cpp:40-44
     settings.depthOfField.enabled = false;
     settings.depthOfField.aperture = 10.0;
@@ -18,6 +18,7 @@ Renderer::Renderer(int w, int h, int tw, int th, const std::string& scene, const
 }
 
 Renderer::~Renderer() {
+    if (group_) rt_scene_group_destroy(group_);
     if (scene_) rt_scene_destroy(scene_);
     if (host_) rt_host_scene_free(host_);
 }
@@ -27,12 +28,17 @@ void Renderer::LoadScene(const std::string& path) {
     check(rt_host_scene_load(path.c_str(), assetDir.empty() ? nullptr : assetDir.c_str(), &hs), "LoadScene");
     for (int i = 0; i < rt_host_scene_warning_count(hs); i++) std::fprintf(stderr, "warning: %s\n", rt_host_scene_warning(hs, i));
     rt_scene* ds = nullptr;
+    rt_scene_group* grp = nullptr;
     int rc = rt_host_scene_set_viewport(hs, width, height);
-    if (rc == RT_OK) rc = rt_scene_create(rt_host_scene_desc(hs), &ds);
+    if (rc == RT_OK) rc = rt_scene_create(rt_host_scene_desc(hs), &ds);  // segments and single-GPU frames
+    if (rc == RT_OK && gpus_ > 1) rc = rt_scene_group_create(rt_host_scene_desc(hs), gpus_, nullptr, &grp);
     if (rc != RT_OK) {
+        if (ds) rt_scene_destroy(ds);
         rt_host_scene_free(hs);
         check(rc, "LoadScene");
     }
+    if (group_) rt_scene_group_destroy(group_);
+    group_ = grp;
     if (scene_) rt_scene_destroy(scene_);
     if (host_) rt_host_scene_free(host_);
     host_ = hs, scene_ = ds, scenePath = path;
@@ -54,7 +60,8 @@ rt_settings Renderer::abiSettings() const {
 void Renderer::Render() {
     rt_settings s = abiSettings();
     pixels.resize((size_t)texture_width * texture_height * 4);
-    check(rt_render_frame(scene_, &s, texture_width, texture_height, width, height, 32, 0, 1, pixels.data(), &lastStats), "Render");
+    if (group_) check(rt_render_frame_multi(group_, &s, texture_width, texture_height, width, height, 32, pixels.data(), &lastStats), "Render");
+    else check(rt_render_frame(scene_, &s, texture_width, texture_height, width, height, 32, 0, 1, pixels.data(), &lastStats), "Render");
 }
 
 bool Renderer::RenderNextSegment() {

@@ -27,8 +27,10 @@ class Renderer {
 public:
     // width/height: camera viewport (CR/Renderer_CUDA.cpp:467 passes them as camera W,H);
     // textureWidth/Height: size of the rendered image.
+    // gpus > 1: frames are rendered by that many GPUs (0 .. gpus-1) through a scene group (rt_render_frame_multi); the
+    // reference knows one GPU only (CR/Renderer.cpp:104).
     Renderer(int width, int height, int textureWidth, int textureHeight, const std::string& scene, const std::string& assetDir = "",
-             int device = 0);
+             int device = 0, int gpus = 1);
     ~Renderer();
     Renderer(const Renderer&) = delete;
     Renderer& operator=(const Renderer&) = delete;
@@ -60,7 +62,8 @@ private:
     rt_settings abiSettings() const;
     rt_host_scene* host_ = nullptr;
     rt_scene* scene_ = nullptr;
-    int device_;
+    rt_scene_group* group_ = nullptr;  // gpus > 1 only
+    int device_, gpus_;
     int x_progress = 0, y_progress = 0;
 };
 #endif

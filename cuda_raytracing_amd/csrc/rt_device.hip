@@ -37,7 +37,7 @@ static_assert(RT_SPEC_POWER == 20, "the specular power is expanded by hand in di
 static_assert(sizeof(DevShade) == 216 && sizeof(DevShade) % 4 == 0, "shading record");
 static_assert(sizeof(DevNode4) == 128 && sizeof(DevGeom) == 192, "device record sizes");
 static_assert(sizeof(rt_primitive) == 408 && sizeof(rt_light) == 112 && sizeof(rt_scene_desc) == 256 && sizeof(rt_settings) == 40 &&
-                  sizeof(rt_stats) == 80,
+                  sizeof(rt_stats) == 88,
               "record sizes are part of the ABI (the Python binding mirrors them)");
 
 struct Tile {
@@ -77,15 +77,12 @@ struct RenderParams {
 #define RT_SHARE_CLOSEST 0  // 1: the shared variant also shares its closest-hit walks (mesh_closest_shared).  Halves the steps of those
                            // walks, but what it costs in registers around them is as much: c4_lucy 43.7 -> 44.8, c5_final 201 -> 197 ms/frame
 #endif
-#ifndef RT_TUNE_BLOCKS
-#define RT_TUNE_BLOCKS 1024  // blocks per variant in the timing sample that picks the shadow-walk variant (2 M paths at 32 spp)
-#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 32  // idle lanes that trigger a refill: the set-up of new paths is long, and running it for one lane costs the same
                           // (measured ms/frame: 8: 52.0, 16: 49.1, 24: 47.7, 32: 47.1, 40: 47.3, 48: 47.8)
 #endif
 
-enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_COUNT,
+enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFETCH, CTR_TRACED, CTR_COUNT,
        // lane-utilisation probes, only counted in -DRT_UTIL_COUNTERS builds (printed by rt_render_* to stderr)
        CTR_U_SHADOW_SLOTS = CTR_COUNT, CTR_U_SHADOW_ITEMS, CTR_U_TRACE_SLOTS, CTR_U_TRACE_ACTIVE, CTR_U_PROBES, CTR_ALL = CTR_U_PROBES + 12 };
 
@@ -172,6 +169,7 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
         const int my_rank = heavy ? rank_in(hmask) : work ? nheavy + rank_in(lmask) : nwork + rank_in(~wmask);
         const int owner_tbl = __builtin_amdgcn_ds_permute(my_rank << 2, lane);  // lane r learns which lane owns slot r
         const int total = nwork * n_l;
+        ctr.traced_wave += (uint32_t)total;  // the shadow rays of this lamp that are intersected with the scene (same value in every lane)
         const float inv_nl = 1.0f / (float)n_l;
         for (int base = 0; base < total; base += 64) {
             const int item = base + lane;
@@ -521,6 +519,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     }
     Counters ctr;
     ctr.rays_secondary = ctr.rays_shadow = ctr.nodes = ctr.tris = ctr.shaded = ctr.texfetch = 0;
+    ctr.traced_wave = 0;
 #ifdef RT_UTIL_COUNTERS
     ctr.u_shadow_slots = ctr.u_shadow_items = ctr.u_trace_slots = ctr.u_trace_active = 0;
     for (int i = 0; i < 12; i++) ctr.u[i] = 0;
@@ -535,12 +534,12 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_REFILL);
     if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);
-    unsigned long long v[CTR_ALL] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch,
+    unsigned long long v[CTR_ALL] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch, 0ull,
                                      ctr.u_shadow_slots, ctr.u_shadow_items, ctr.u_trace_slots, ctr.u_trace_active,
                                      ctr.u[0], ctr.u[1], ctr.u[2], ctr.u[3], ctr.u[4], ctr.u[5], ctr.u[6], ctr.u[7], ctr.u[8], ctr.u[9], ctr.u[10], ctr.u[11]};
     const int n_ctr = CTR_ALL;
 #else
-    unsigned long long v[CTR_COUNT] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch};
+    unsigned long long v[CTR_COUNT] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch, 0ull};
     const int n_ctr = CTR_COUNT;
 #endif
 #pragma unroll
@@ -548,6 +547,7 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
         unsigned long long s = wave_sum_u64(v[i]);
         if (lane == 0 && s) atomicAdd(&P.counters[i], s);
     }
+    if (lane == 0 && ctr.traced_wave) atomicAdd(&P.counters[CTR_TRACED], (unsigned long long)ctr.traced_wave);
 }
 
 // ---- pixel sums: CR/RayTracer.cu:74-89 ---------------------------------------------------------
@@ -610,23 +610,27 @@ static thread_local hipStream_t g_stream = nullptr;
         if (e_ != hipSuccess) return rt_fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Device memory a render call works in besides the scene, the image and the caller's buffers.
+struct Workspace {
+    uint32_t* queue = nullptr;               // 64 words: heads of the eight ranges of the path queue
+    unsigned long long* counters = nullptr;  // CTR_ALL + 16 work counters
+    BlockRec* blocks = nullptr;              // the 8x8 blocks of the call, in queue order
+    size_t blocks_cap = 0;
+    double* path_out = nullptr;              // colours of the finished paths of one launch
+    size_t path_out_bytes = 0;
+    bool fixed = false;                      // true: the buffers above are all there is (nothing may be allocated or grown)
+};
+
 struct rt_scene {
     int device = 0;
     DevScene dev{};
     void* slab = nullptr;
     size_t slab_bytes = 0;
-    uint32_t* queue = nullptr;             // work-queue head
-    unsigned long long* counters = nullptr;  // CTR_COUNT work counters
+    Workspace ws;                          // queue heads, counters, block list, path colours: allocated at first use, grown on demand
     uint8_t* image = nullptr;              // staging image for host destinations
     size_t image_bytes = 0;
-    double* path_out = nullptr;            // colours of the finished paths of one launch
-    size_t path_out_bytes = 0;
-    int shared_walk = -1;                  // shadow mesh walks shared by the wave: -1 = not decided yet, 0 = no, 1 = yes
-    float tune_ms[2] = {0.0f, 0.0f};       // the timings behind that decision (plain, shared)
-    BlockRec* tune_blocks = nullptr;       // 2 * RT_TUNE_BLOCKS blocks: the two timing samples
-    hipEvent_t ev_tune[2] = {nullptr, nullptr};
-    BlockRec* blocks = nullptr;            // 8x8 blocks of the tiles of the last call, in queue order
-    size_t blocks_cap = 0, n_blocks = 0;
+    int shared_walk = 0;                   // shadow mesh walks shared by the wave (render_kernel<.., SHARE = true>): 0 = no, 1 = yes
+    size_t n_blocks = 0;                   // blocks in ws.blocks: those of last_tiles
     std::vector<Tile> last_tiles;
     int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -711,14 +715,11 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->slab) (void)hipFree(s->slab);
-    if (s->queue) (void)hipFree(s->queue);
-    if (s->counters) (void)hipFree(s->counters);
+    if (s->ws.queue) (void)hipFree(s->ws.queue);
+    if (s->ws.counters) (void)hipFree(s->ws.counters);
     if (s->image) (void)hipFree(s->image);
-    if (s->path_out) (void)hipFree(s->path_out);
-    if (s->blocks) (void)hipFree(s->blocks);
-    if (s->tune_blocks) (void)hipFree(s->tune_blocks);
-    if (s->ev_tune[0]) (void)hipEventDestroy(s->ev_tune[0]);
-    if (s->ev_tune[1]) (void)hipEventDestroy(s->ev_tune[1]);
+    if (s->ws.path_out) (void)hipFree(s->ws.path_out);
+    if (s->ws.blocks) (void)hipFree(s->ws.blocks);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -834,13 +835,16 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.cand_grid = cgrid.empty() ? nullptr : (const unsigned long long*)(base + off_cg);
     for (int k = 0; k < 3; k++) v.cg_lo[k] = cg_lo[k], v.cg_inv[k] = cg_inv[k];
 
-    HIPCHK(hipMalloc(&s->queue, 256));
-    HIPCHK(hipMalloc(&s->counters, sizeof(unsigned long long) * (CTR_ALL + 16)));
+    HIPCHK(hipMalloc(&s->ws.queue, 256));
+    HIPCHK(hipMalloc(&s->ws.counters, sizeof(unsigned long long) * (CTR_ALL + 16)));
     HIPCHK(hipEventCreate(&s->ev0));
     HIPCHK(hipEventCreate(&s->ev1));
-    HIPCHK(hipEventCreate(&s->ev_tune[0]));
-    HIPCHK(hipEventCreate(&s->ev_tune[1]));
-    HIPCHK(hipMalloc(&s->tune_blocks, 2 * RT_TUNE_BLOCKS * sizeof(BlockRec)));
+    // Which variant of the shadow mesh walk the scene gets.  Sharing pays where shadow rays walk meshes at all (c5_final:
+    // 265 -> 198 ms per frame) and costs nothing measurable where they rarely do (c4_lucy: 43.3 vs 43.2 ms), so the rule is
+    // static: scenes with a four-wide tree get the shared variant.  RT_AMD_SHARED_WALK=0|1 overrides it.
+    s->shared_walk = (v.mesh_scale_max > 0.0 && v.n_prims <= RT_SHADE_LDS) ? 1 : 0;
+    if (const char* e = std::getenv("RT_AMD_SHARED_WALK"))
+        if ((e[0] == '0' || e[0] == '1') && v.n_prims <= RT_SHADE_LDS) s->shared_walk = e[0] - '0';
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     s->cus = prop.multiProcessorCount;
@@ -867,49 +871,58 @@ static int check_common(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     return RT_OK;
 }
 
+// The 8x8 blocks of the tiles in Z-order: blocks that follow each other in the queue are neighbours in the image,
+// and each of the eight ranges of the queue is a compact region (its rays meet the same part of the scene in L2).
+static int blocks_of(const std::vector<Tile>& tiles, std::vector<BlockRec>& recs) {
+    auto spread = [](uint32_t v) {
+        v &= 0xFFFFu;
+        v = (v | (v << 8)) & 0x00FF00FFu, v = (v | (v << 4)) & 0x0F0F0F0Fu, v = (v | (v << 2)) & 0x33333333u, v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    std::vector<std::pair<uint32_t, BlockRec>> keyed;
+    for (const Tile& t : tiles) {
+        for (int by = 0; by < t.h; by += 8)
+            for (int bx = 0; bx < t.w; bx += 8) {
+                BlockRec r;
+                r.x0 = (uint16_t)(t.x0 + bx), r.y0 = (uint16_t)(t.y0 + by);
+                r.w = (uint8_t)std::min(8, t.w - bx), r.h = (uint8_t)std::min(8, t.h - by), r.pad_ = 0;
+                keyed.push_back({spread((uint32_t)r.x0 >> 3) | (spread((uint32_t)r.y0 >> 3) << 1), r});
+            }
+        if (keyed.size() >= (1ull << 24)) return rt_fail(RT_ERR_LIMIT, "too many pixels in one call");
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    recs.resize(keyed.size());
+    for (size_t i = 0; i < keyed.size(); i++) recs[i] = keyed[i].second;
+    return RT_OK;
+}
+
 // Render the given tiles into `dst` (device image).  Fills kernel time and counters.
-static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, const std::vector<Tile>& tiles,
-                        uint8_t* dst, rt_stats* stats) {
-    // The 8x8 blocks of the tiles in Z-order: blocks that follow each other in the queue are neighbours in the image,
-    // and each of the eight ranges of the queue is a compact region (its rays meet the same part of the scene in L2).
-    // The list is kept from call to call: a renderer asks for the same tiles frame after frame.
+static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h,
+                        const std::vector<Tile>& tiles, uint8_t* dst, rt_stats* stats) {
     uint64_t pixels = 0;
     for (const Tile& t : tiles) pixels += (uint64_t)t.w * t.h;
-    const bool same_tiles = s->last_tiles.size() == tiles.size() &&
+    // The block list of the scene's own workspace is kept from call to call: a renderer asks for the same tiles frame after frame.
+    const bool same_tiles = !ws.fixed && s->last_tiles.size() == tiles.size() &&
                             (tiles.empty() || std::memcmp(s->last_tiles.data(), tiles.data(), tiles.size() * sizeof(Tile)) == 0);
+    uint64_t blocks = s->n_blocks;
     if (!same_tiles) {
-        auto spread = [](uint32_t v) {
-            v &= 0xFFFFu;
-            v = (v | (v << 8)) & 0x00FF00FFu, v = (v | (v << 4)) & 0x0F0F0F0Fu, v = (v | (v << 2)) & 0x33333333u, v = (v | (v << 1)) & 0x55555555u;
-            return v;
-        };
-        std::vector<std::pair<uint32_t, BlockRec>> keyed;
-        for (const Tile& t : tiles) {
-            for (int by = 0; by < t.h; by += 8)
-                for (int bx = 0; bx < t.w; bx += 8) {
-                    BlockRec r;
-                    r.x0 = (uint16_t)(t.x0 + bx), r.y0 = (uint16_t)(t.y0 + by);
-                    r.w = (uint8_t)std::min(8, t.w - bx), r.h = (uint8_t)std::min(8, t.h - by), r.pad_ = 0;
-                    keyed.push_back({spread((uint32_t)r.x0 >> 3) | (spread((uint32_t)r.y0 >> 3) << 1), r});
-                }
-            if (keyed.size() >= (1ull << 24)) return rt_fail(RT_ERR_LIMIT, "too many pixels in one call");
-        }
-        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-        std::vector<BlockRec> recs(keyed.size());
-        for (size_t i = 0; i < keyed.size(); i++) recs[i] = keyed[i].second;
-        if (recs.size() > s->blocks_cap) {
-            if (s->blocks) (void)hipFree(s->blocks);
-            s->blocks = nullptr, s->blocks_cap = 0;
+        std::vector<BlockRec> recs;
+        int rc = blocks_of(tiles, recs);
+        if (rc) return rc;
+        if (recs.size() > ws.blocks_cap) {
+            if (ws.fixed) return rt_fail(RT_ERR_LIMIT, "rectangle has more 8x8 pixel blocks than the fixed workspace holds");
+            if (ws.blocks) (void)hipFree(ws.blocks);
+            ws.blocks = nullptr, ws.blocks_cap = 0;
             const size_t cap = recs.size() + 1024;
-            HIPCHK(hipMalloc(&s->blocks, cap * sizeof(BlockRec)));
-            s->blocks_cap = cap;
+            HIPCHK(hipMalloc(&ws.blocks, cap * sizeof(BlockRec)));
+            ws.blocks_cap = cap;
         }
-        s->last_tiles.clear();  // stays empty if the copy fails
-        if (!recs.empty()) HIPCHK(hipMemcpy(s->blocks, recs.data(), recs.size() * sizeof(BlockRec), hipMemcpyHostToDevice));
-        s->last_tiles = tiles;
-        s->n_blocks = recs.size();
+        if (!ws.fixed) s->last_tiles.clear();  // stays empty if the copy fails
+        if (!recs.empty()) HIPCHK(hipMemcpyAsync(ws.blocks, recs.data(), recs.size() * sizeof(BlockRec), hipMemcpyHostToDevice, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));  // `recs` goes out of scope
+        blocks = recs.size();
+        if (!ws.fixed) s->last_tiles = tiles, s->n_blocks = recs.size();
     }
-    const uint64_t blocks = s->n_blocks;
     const bool strict = (st->flags & RT_F_STRICT_TRAVERSAL) != 0;
     const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
     // blocks per launch: the colours of all paths of a launch are kept until its pixel sums are taken
@@ -919,15 +932,21 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v >= 64 && v < launch_paths) launch_paths = v;
     }
+    if (ws.fixed) {
+        const uint64_t cap = ws.path_out_bytes / (3 * sizeof(double));
+        if (cap < block_paths) return rt_fail(RT_ERR_LIMIT, "too many samples per pixel for the fixed workspace (one 8x8 block must fit)");
+        launch_paths = std::min(launch_paths, cap);
+    }
     const uint64_t chunk_blocks = std::max<uint64_t>(1, launch_paths / block_paths);
     const size_t out_bytes = (size_t)(std::min(blocks, chunk_blocks) * block_paths) * 3 * sizeof(double);
-    if (s->path_out_bytes < out_bytes) {
-        if (s->path_out) (void)hipFree(s->path_out);
-        s->path_out = nullptr, s->path_out_bytes = 0;
-        HIPCHK(hipMalloc(&s->path_out, out_bytes));
-        s->path_out_bytes = out_bytes;
+    if (ws.path_out_bytes < out_bytes) {
+        if (ws.fixed) return rt_fail(RT_ERR_LIMIT, "fixed workspace too small");  // not reached: chunk_blocks was cut to fit
+        if (ws.path_out) (void)hipFree(ws.path_out);
+        ws.path_out = nullptr, ws.path_out_bytes = 0;
+        HIPCHK(hipMalloc(&ws.path_out, out_bytes));
+        ws.path_out_bytes = out_bytes;
     }
-    HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));
+    HIPCHK(hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));
 
     RenderParams P;
     P.sc = s->dev;
@@ -937,13 +956,14 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     P.focal = st->focal_distance, P.aperture = st->aperture;
     P.inv_block_paths = 1.0 / (double)block_paths * (1.0 + 1e-12), P.inv_spp = 1.0 / (double)st->spp * (1.0 + 1e-12);
     P.k0 = (uint32_t)st->seed, P.k1 = (uint32_t)(st->seed >> 32), P.flags = st->flags;
-    P.queue = s->queue, P.out = dst, P.counters = s->counters, P.path_out = s->path_out;
+    P.queue = ws.queue, P.out = dst, P.counters = ws.counters, P.path_out = ws.path_out;
 
-    // one launch: the blocks [first, first + nb) of `list`, traced and resolved
-    auto launch = [&](const BlockRec* list, uint64_t first, uint64_t nb, bool share) -> int {
-        P.blocks = list + first, P.n_blocks = (uint32_t)nb, P.n_paths = (uint32_t)(nb * block_paths);
+    const bool share = !strict && s->shared_walk == 1;
+    // one launch: the blocks [first, first + nb) of the list, traced and resolved
+    auto launch = [&](uint64_t first, uint64_t nb) -> int {
+        P.blocks = ws.blocks + first, P.n_blocks = (uint32_t)nb, P.n_paths = (uint32_t)(nb * block_paths);
         P.range_paths = (uint32_t)(((nb + 7) / 8) * block_paths);
-        HIPCHK(hipMemsetAsync(s->queue, 0, 256, g_stream));
+        HIPCHK(hipMemsetAsync(ws.queue, 0, 256, g_stream));
         // persistent grid: every wave draws paths until the launch runs dry
         uint64_t grid = (uint64_t)s->cus * bpc;
         const uint64_t want_blocks = ((uint64_t)P.n_paths + 255) / 256;
@@ -961,45 +981,13 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         return RT_OK;
     };
     HIPCHK(hipEventRecord(s->ev0, g_stream));
-    uint64_t done = 0;
-    // Which variant of the shadow mesh walk this scene gets is decided once, by timing: two equal samples of the frame's blocks
-    // (every other block of its first part) are rendered with one variant each; the rest of the frame and all later calls use
-    // the faster one.  Both variants give the same image, so the choice only costs two short launches.
-    if (!strict && s->shared_walk < 0) {
-        const char* e = std::getenv("RT_AMD_SHARED_WALK");
-        if (e && (e[0] == '0' || e[0] == '1')) s->shared_walk = e[0] - '0';
-        else if (s->dev.mesh_scale_max <= 0.0 || s->dev.n_prims > RT_SHADE_LDS) s->shared_walk = 0;  // nothing to share, or no variant built
-    }
-    const uint64_t sample = std::min<uint64_t>(std::min<uint64_t>(RT_TUNE_BLOCKS, chunk_blocks), blocks / 8);  // an eighth of the call at most, per variant
-    if (!strict && s->shared_walk < 0 && sample >= 128 && s->tune_blocks) {
-        std::vector<BlockRec> head(2 * sample), split(2 * sample);
-        HIPCHK(hipMemcpy(head.data(), s->blocks, head.size() * sizeof(BlockRec), hipMemcpyDeviceToHost));
-        for (uint64_t i = 0; i < sample; i++) split[i] = head[2 * i], split[sample + i] = head[2 * i + 1];
-        HIPCHK(hipMemcpy(s->tune_blocks, split.data(), split.size() * sizeof(BlockRec), hipMemcpyHostToDevice));
-        float ms[2] = {0.0f, 0.0f};
-        for (int round = 0; round < 2; round++) {  // the first round warms up caches, code and scratch; the second is timed
-            for (int v = 0; v < 2; v++) {
-                HIPCHK(hipEventRecord(s->ev_tune[0], g_stream));
-                int rc = launch(s->tune_blocks, v * sample, sample, v == 1);
-                if (rc) return rc;
-                HIPCHK(hipEventRecord(s->ev_tune[1], g_stream));
-                HIPCHK(hipEventSynchronize(s->ev_tune[1]));
-                HIPCHK(hipEventElapsedTime(&ms[v], s->ev_tune[0], s->ev_tune[1]));
-            }
-            if (round == 0) HIPCHK(hipMemsetAsync(s->counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));  // its rays are not the frame's
-        }
-        s->shared_walk = ms[1] < 0.99f * ms[0] ? 1 : 0;  // the plain variant unless sharing is faster by more than the timing noise
-        s->tune_ms[0] = ms[0], s->tune_ms[1] = ms[1];
-        done = 2 * sample;
-    }
-    const bool share = !strict && s->shared_walk == 1;
-    for (uint64_t b0 = done; b0 < blocks; b0 += chunk_blocks) {
-        int rc = launch(s->blocks, b0, std::min(chunk_blocks, blocks - b0), share);
+    for (uint64_t b0 = 0; b0 < blocks; b0 += chunk_blocks) {
+        int rc = launch(b0, std::min(chunk_blocks, blocks - b0));
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(s->ev1, g_stream));
     unsigned long long c[CTR_ALL + 16];
-    HIPCHK(hipMemcpyAsync(c, s->counters, sizeof(c), hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(c, ws.counters, sizeof(c), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
 #ifdef RT_UTIL_COUNTERS
     std::fprintf(stderr, "[util] shadow lanes used %.1f%% (%llu of %llu slots), closest-hit lanes used %.1f%% (%llu of %llu slots)\n",
@@ -1014,8 +1002,10 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
     for (int k = 0; k < PF_COUNT; k++) tot += c[CTR_ALL + k];
     for (int k = 0; k < PF_COUNT; k++)
         std::fprintf(stderr, "[time] %-26s %5.1f%%\n", sect[k], 100.0 * c[CTR_ALL + k] / (double)(tot ? tot : 1));
+#ifndef RT_PROBE_STEPS
     std::fprintf(stderr, "[util] shadow rays traced because of: sphere/plane/square %llu (only: %llu), cylinder/bezier %llu (only: %llu), mesh %llu (only: %llu)\n",
                  c[CTR_U_PROBES + 6], c[CTR_U_PROBES + 7], c[CTR_U_PROBES + 8], c[CTR_U_PROBES + 9], c[CTR_U_PROBES + 10], c[CTR_U_PROBES + 11]);
+#endif
     for (int k = 0; k < RT_PROBE_KINDS; k++) {
         const unsigned long long lanes = c[CTR_U_PROBES + 2 * k], slots = c[CTR_U_PROBES + 2 * k + 1];
         std::fprintf(stderr, "[util] %-24s lanes %.1f%% (%llu lane executions, %llu wave executions)\n", probe_name[k],
@@ -1031,6 +1021,7 @@ static int launch_tiles(rt_scene* s, const rt_settings* st, int tex_w, int tex_h
         stats->rays_secondary = c[CTR_SECONDARY], stats->rays_shadow = c[CTR_SHADOW];
         stats->nodes_visited = c[CTR_NODES], stats->tris_tested = c[CTR_TRIS];
         stats->shaded_hits = c[CTR_SHADED], stats->texture_fetches = c[CTR_TEXFETCH];
+        stats->rays_shadow_traced = c[CTR_TRACED];
     }
     return RT_OK;
 }
@@ -1052,12 +1043,12 @@ static int render_common(rt_scene* s, const rt_settings* st, int tex_w, int tex_
     const size_t bytes = (size_t)tex_w * tex_h * 4;
     int rc;
     if (is_device_ptr(rgba)) {
-        rc = launch_tiles(s, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba, stats);
+        rc = launch_tiles(s, s->ws, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba, stats);
         if (rc) return rc;
     } else {
         rc = ensure_image(s, bytes);
         if (rc) return rc;
-        rc = launch_tiles(s, st, tex_w, tex_h, cam_w, cam_h, tiles, s->image, stats);
+        rc = launch_tiles(s, s->ws, st, tex_w, tex_h, cam_w, cam_h, tiles, s->image, stats);
         if (rc) return rc;
         // copy back only the rows of the rendered rectangles; other pixels of the caller's image stay
         for (const Tile& t : tiles) {
@@ -1140,3 +1131,5 @@ extern "C" int rt_trace_primary(rt_scene* s, const rt_settings* st, int tex_w, i
     if (e != hipSuccess) return rt_fail(RT_ERR_DEVICE, std::string("rt_trace_primary: ") + hipGetErrorString(e));
     return RT_OK;
 }
+
+#include "rt_multi.hpp"

@@ -13,15 +13,16 @@
 static void usage() {
     std::fprintf(stderr,
                  "usage: rt_render --scene FILE [--assets DIR] [--out FILE.bmp] [--size WxH] [--viewport WxH]\n"
-                 "                 [--spp N] [--dof APERTURE FOCAL] [--seed S] [--mode gpu|cpu] [--strict] [--device D]\n"
+                 "                 [--spp N] [--dof APERTURE FOCAL] [--seed S] [--mode gpu|cpu] [--strict] [--device D] [--gpus N]\n"
                  "                 [--progressive N [--sequence PREFIX]]\n"
+                 "  --gpus N          render whole frames on GPUs 0 .. N-1 (tiles interleaved over them, gathered on GPU 0)\n"
                  "  --progressive N   render the frame as N x N segments, one call each, with a progress line per segment\n"
                  "  --sequence PREFIX also write PREFIX_0001.bmp, ... after every row of segments\n");
 }
 
 int main(int argc, char** argv) {
     std::string scene, assets, out = "output.bmp", mode = "gpu", sequence;
-    int tw = 1920, th = 1080, vw = 0, vh = 0, spp = 1, device = 0, progressive = 0;
+    int tw = 1920, th = 1080, vw = 0, vh = 0, spp = 1, device = 0, progressive = 0, gpus = 1;
     bool dof = false, strict = false;
     double aperture = 10, focal = 10;
     unsigned long long seed = 1;
@@ -43,6 +44,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--mode")) need(1), mode = argv[++i];
         else if (!std::strcmp(argv[i], "--strict")) strict = true;
         else if (!std::strcmp(argv[i], "--device")) need(1), device = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--gpus")) need(1), gpus = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--progressive")) need(1), progressive = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--sequence")) need(1), sequence = argv[++i];
         else {
@@ -56,7 +58,7 @@ int main(int argc, char** argv) {
     }
     if (vw <= 0 || vh <= 0) vw = tw, vh = th;
     try {
-        Renderer r(vw, vh, tw, th, scene, assets, device);
+        Renderer r(vw, vh, tw, th, scene, assets, device, gpus);
         r.seed = seed;
         r.mode = (mode == "cpu" ? RT_MODE_CPU_REF : RT_MODE_GPU_REF) | (strict ? RT_F_STRICT_TRAVERSAL : 0u);
         r.settings.resampling_size = spp;

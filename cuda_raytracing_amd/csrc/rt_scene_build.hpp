@@ -64,8 +64,9 @@ struct Tree4 {
     std::vector<int32_t> mesh_root4;                  // per mesh: root DevNode4 index, -1 = use the stackless walk
     std::vector<TreeJob> jobs;
 };
-static int g_tree_builder = 0;  // 0 = host (binned surface-area heuristic), 1 = device (Morton order, balanced)
-static bool g_tree_builder_set = false;
+// set by rt_set_tree_builder for the calling thread (like the render stream), read by that thread's next rt_scene_create
+static thread_local int g_tree_builder = 0;  // 0 = host (binned surface-area heuristic), 1 = device (Morton order, balanced)
+static thread_local bool g_tree_builder_set = false;
 
 // double-precision bounds of what hangs under a child ref: the reference's box of an interior node, the
 // triangle's own bounds for a leaf

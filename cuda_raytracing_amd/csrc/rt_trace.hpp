@@ -116,6 +116,7 @@ struct Hit {  // CR/Primitive.cuh:107-113
 
 struct Counters {  // per-lane work counters, flushed once per wave
     uint32_t rays_secondary, rays_shadow, nodes, tris, shaded, texfetch;
+    uint32_t traced_wave;  // shadow rays of the whole wave that were intersected with the scene: wave-uniform, lane 0 flushes it
 #ifdef RT_UTIL_COUNTERS
     uint32_t u_shadow_slots, u_shadow_items, u_trace_slots, u_trace_active;
     uint32_t u[12];  // pairs (lane executions, 64 x wave executions): shadow mesh calls, closest mesh calls, then interior / leaf steps of each
@@ -714,6 +715,12 @@ DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d
 #ifndef RT_SHARE_STEPS
 #define RT_SHARE_STEPS 2  // interior steps between two looks at who is idle (1: 207, 2: 201, 4: 211)
 #endif
+// Mesh roots a ray may put on its stack before the shared walk starts.  A four-wide tree is at most RT_STACK / 3 levels
+// deep and a walk pushes up to three siblings per level, so the walk of one tree needs 3 * (RT_STACK / 3) entries; the
+// roots that wait below it must fit in what is left, or a push would be dropped and an occluder missed.  Further
+// candidate meshes of the same ray are walked by the lane on its own.
+#define RT_SHARED_ROOTS (RT_STACK - 3 * (RT_STACK / 3) + 1)  // the root being walked has left the stack
+static_assert(RT_SHARED_ROOTS >= 1 && (RT_SHARED_ROOTS - 1) + 3 * (RT_STACK / 3) <= RT_STACK, "roots + one tree walk fit the stack");
 // On entry the lane's stack (sp entries) holds the roots of the meshes its ray may enter; `S` = the largest mesh scale
 // of the scene (it only widens the error bounds).  The ray is passed by value and overwritten by hand-overs.
 DEV bool mesh_anyhit_shared(const DevScene& sc, double S, int sp, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk, uint32_t* xch) {
@@ -1381,7 +1388,7 @@ DEV bool shadow_clear_shared(const DevScene& sc, uint32_t flags, bool act, d3 C,
                 const d3 inv = D3(1.0 / dm.x, 1.0 / dm.y, 1.0 / dm.z);
                 const double S = g.f[MSH_SCALE];
                 const double mm = fmax(fmax((S + fabs(C.x)) * fabs(inv.x), (S + fabs(C.y)) * fabs(inv.y)), (S + fabs(C.z)) * fabs(inv.z));
-                if (!g.aux2 || sp >= RT_STACK / 4 || !(mm < 1e30) || !(fabs(inv.x) < 1e30) || !(fabs(inv.y) < 1e30) || !(fabs(inv.z) < 1e30)) {
+                if (!g.aux2 || sp >= RT_SHARED_ROOTS || !(mm < 1e30) || !(fabs(inv.x) < 1e30) || !(fabs(inv.y) < 1e30) || !(fabs(inv.z) < 1e30)) {
                     // (also: a mesh without a four-wide tree, a ray with more candidate meshes than roots are kept for)
                     t = mesh_walk<false, true, false>(sc, g.aux0, C, dm, dist, S, ctr, nullptr, 0, dummy_n, 0).t;
                 } else {

@@ -170,8 +170,8 @@ extern "C" int rt_set_tree_builder(int which) {
 extern "C" double rt_scene_tree_build_ms(const rt_scene* s) { return s ? (double)s->tree_build_ms : 0.0; }
 extern "C" int rt_scene_shared_walk(const rt_scene* s, double* plain_ms, double* shared_ms) {
     if (!s) return -1;
-    if (plain_ms) *plain_ms = s->tune_ms[0];
-    if (shared_ms) *shared_ms = s->tune_ms[1];
+    if (plain_ms) *plain_ms = 0.0;  // the choice is made from the scene's contents, nothing is timed
+    if (shared_ms) *shared_ms = 0.0;
     return s->shared_walk;
 }
 

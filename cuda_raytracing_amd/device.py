@@ -96,3 +96,54 @@ class DeviceScene:
         abi.check(self._lib.rt_trace_primary(self._h, C.byref(st), tex_w, tex_h, cw, ch, x0, y0, w, h, hit.ctypes.data, t.ctypes.data,
                                              leaf.ctypes.data, log.ctypes.data if visit_cap else None, cnt.ctypes.data, visit_cap))
         return hit, t, leaf, log, cnt
+
+
+class SceneGroup:
+    """rt_scene_group: the scene on several GPUs of this process; `render_frame` is rt_render_frame_multi."""
+
+    def __init__(self, host_scene, n_gpus=None, devices=None):
+        import torch  # noqa: F401  plumbing: loads the HIP runtime that librt_amd.so then binds to
+
+        self._lib = abi.load_library()
+        if devices is not None:
+            n_gpus = len(devices)
+            arr = (C.c_int * n_gpus)(*devices)
+        else:
+            n_gpus = n_gpus or int(self._lib.rt_device_count())
+            arr = None
+        self._h = C.c_void_p()
+        abi.check(self._lib.rt_scene_group_create(host_scene.desc_ptr, n_gpus, arr, C.byref(self._h)))
+        self.host = host_scene
+
+    @property
+    def size(self):
+        return int(self._lib.rt_scene_group_size(self._h))
+
+    @property
+    def member_ms(self):
+        return [float(self._lib.rt_scene_group_member_ms(self._h, k)) for k in range(self.size)]
+
+    def render_frame(self, st, tex_w, tex_h, cam=None, tile=32, out=None):
+        cw, ch = cam or (tex_w, tex_h)
+        if out is None:
+            out = np.zeros((tex_h, tex_w, 4), dtype=np.uint8)
+        stats = abi.Stats()
+        abi.check(self._lib.rt_render_frame_multi(self._h, C.byref(st), tex_w, tex_h, cw, ch, tile, DeviceScene._ptr(out), C.byref(stats)))
+        return out, stats
+
+    def close(self):
+        if self._h:
+            self._lib.rt_scene_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

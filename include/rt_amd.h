@@ -192,7 +192,7 @@ typedef struct rt_settings {
 typedef struct rt_stats {
     uint64_t rays_primary;   /* one per pixel sample                                   */
     uint64_t rays_secondary; /* reflect + refract rays that were intersected           */
-    uint64_t rays_shadow;    /* one per light sample per shaded hit                    */
+    uint64_t rays_shadow;    /* one per light sample per shaded hit, traced or not (see rays_shadow_traced) */
     uint64_t nodes_visited;  /* interior boxes tested + leaves reached                 */
     uint64_t tris_tested;    /* leaf triangles tested                                  */
     uint64_t shaded_hits;    /* CalnDiffusion evaluations                              */
@@ -200,6 +200,10 @@ typedef struct rt_stats {
     uint64_t pixels;
     double kernel_ms;        /* HIP-event time of the render kernel(s) on the render stream */
     double total_ms;         /* wall time of the call                                  */
+    uint64_t rays_shadow_traced; /* of rays_shadow: those that were intersected with the scene.  The rest were
+                                  * decided without a ray (lamp behind the surface, nothing that could stand
+                                  * between point and lamp, point inside an umbra); the reference traces every
+                                  * one, and so do the oracle and RT_F_STRICT_TRAVERSAL: there the two are equal */
 } rt_stats;
 
 /* ---- host scene model: replaces Raytracer::SetInput/CreateAll (CR/raytracer.cpp:195-275),
@@ -230,7 +234,8 @@ int rt_init(int device);
 /* Render on `stream` (a hipStream_t cast to void*, NULL = the null stream) from now on. */
 int rt_set_stream(void* hip_stream);
 
-/* Who builds the four-wide trees the pruned traversal walks, from the next rt_scene_create on:
+/* Who builds the four-wide trees the pruned traversal walks, from the calling thread's next rt_scene_create on
+ * (the setting belongs to the thread, like the render stream):
  * 0 = the host (binned surface-area heuristic, the default), 1 = the device (triangles in Morton
  * order, cut top-down where the code changes; a few ms instead of tens, somewhat slower to walk).  The
  * image does not depend on the choice.  The reference builds its one tree on the CPU
@@ -240,11 +245,11 @@ int rt_set_tree_builder(int which);
 /* Device time of the last scene's tree build in ms (0 when the host built the trees). */
 double rt_scene_tree_build_ms(const rt_scene* scene);
 /* The render kernel exists in two variants that differ in how shadow rays walk the meshes (each ray on
- * its own lane, or long walks shared out over idle lanes); they give the same image.  A scene gets the
- * faster one: the first large pruned render times both on two equal samples of the frame's blocks.
- * Returns the choice (-1 = not made yet, 0 = plain, 1 = shared) and the two sample times in ms (0 if no
- * timing took place).  RT_AMD_SHARED_WALK=0|1 in the environment fixes the choice.  No counterpart in
- * the reference. */
+ * its own lane, or long walks shared out over idle lanes); they give the same image.  The choice is made
+ * at rt_scene_create from the scene's contents: scenes with meshes get the shared variant (it is faster
+ * wherever shadow rays walk meshes, and as fast elsewhere).  Returns the choice (0 = plain, 1 = shared);
+ * the two times are always 0 (nothing is timed).  RT_AMD_SHARED_WALK=0|1 in the environment overrides
+ * the rule.  No counterpart in the reference. */
 int rt_scene_shared_walk(const rt_scene* scene, double* plain_ms, double* shared_ms);
 
 /* Upload a scene: one slab, one copy.  Replaces createCudaSceneFromCPUScene
@@ -266,6 +271,35 @@ int rt_render_tile(rt_scene* scene, const rt_settings* settings, int tex_w, int 
  * The image does not depend on the partition: the RNG is keyed by pixel and sample. */
 int rt_render_frame(rt_scene* scene, const rt_settings* settings, int tex_w, int tex_h, int cam_w,
                     int cam_h, int tile, int part, int n_parts, uint8_t* rgba, rt_stats* stats);
+
+/* ---- several GPUs in one process --------------------------------------------------------------
+ * launchRayTraceKernelParallel (CR/RayTracer.cuh:13, CR/RayTracer.cu:134-169) renders the whole frame
+ * with one call on the one GPU the reference knows (cudaSetDevice(0), CR/Renderer.cpp:104).  A scene
+ * group is that call for n GPUs: the scene is uploaded to each, the image is cut into tile x tile
+ * squares, tile t (row-major) is rendered by member t % n, and the members' tiles are copied GPU to GPU
+ * into the first member's frame.  The frame is bit-identical for every n. */
+typedef struct rt_scene_group rt_scene_group;
+int rt_device_count(void);
+/* devices = NULL selects GPUs 0 .. n_gpus-1; otherwise devices[k] is the GPU of member k (a GPU may be
+ * named more than once: its members then share it, which is only useful for testing).  Replaces
+ * createCudaSceneFromCPUScene (CR/Renderer_CUDA.cpp:298-335) once per GPU. */
+int rt_scene_group_create(const rt_scene_desc* desc, int n_gpus, const int* devices, rt_scene_group** out);
+void rt_scene_group_destroy(rt_scene_group* group);
+int rt_scene_group_size(const rt_scene_group* group);
+/* Kernel time of one member in the last rt_render_frame_multi, in ms. */
+double rt_scene_group_member_ms(const rt_scene_group* group, int member);
+/* One frame on all GPUs of the group.  `rgba`: host memory, or device memory on the first member's GPU.
+ * `stats` (may be NULL): counters summed over the members, kernel_ms = the slowest member's. */
+int rt_render_frame_multi(rt_scene_group* group, const rt_settings* settings, int tex_w, int tex_h,
+                          int cam_w, int cam_h, int tile, uint8_t* rgba, rt_stats* stats);
+/* The copy kernels of that exchange on their own, for hosts that run one process per GPU and move the
+ * packed tiles themselves (RCCL gather): pack the pixels of the tiles owned by `part` out of a frame
+ * into a contiguous buffer (tiles in row-major order, each tile row by row), or write such a buffer
+ * back into a frame.  Device pointers, on the calling thread's current GPU and stream.
+ * rt_member_pixels gives the number of pixels (4 bytes each) of a part, -1 on bad arguments. */
+long long rt_member_pixels(int tex_w, int tex_h, int tile, int part, int n_parts);
+int rt_pack_tiles(const uint8_t* image_device, int tex_w, int tex_h, int tile, int part, int n_parts, uint8_t* packed_device);
+int rt_unpack_tiles(const uint8_t* packed_device, int tex_w, int tex_h, int tile, int part, int n_parts, uint8_t* image_device);
 
 /* Debug/parity: trace only the primary ray (sample 0, no jitter, no depth of field) of every
  * pixel of the rectangle.  hit_prim[i] = primitive index or -1, hit_t[i] = distance,

@@ -791,6 +791,7 @@ static void stats_add(rt_stats* a, const rt_stats* b) {
     a->rays_primary += b->rays_primary, a->rays_secondary += b->rays_secondary, a->rays_shadow += b->rays_shadow;
     a->nodes_visited += b->nodes_visited, a->tris_tested += b->tris_tested, a->shaded_hits += b->shaded_hits;
     a->texture_fetches += b->texture_fetches, a->pixels += b->pixels;
+    a->rays_shadow_traced += b->rays_shadow;  /* every shadow ray is traced here, as in the reference */
 }
 
 static int ctx_setup(ctx_t* cx, const rt_scene_desc* sc, const rt_settings* s, int cam_w, int cam_h) {

@@ -28,7 +28,7 @@ def test_struct_sizes_match_the_header():
     assert ctypes.sizeof(abi.BvhNode) == 64 and ctypes.sizeof(abi.BvhLeaf) == 96
     assert ctypes.sizeof(abi.Material) == 104 and ctypes.sizeof(abi.Settings) == 40
     assert ctypes.sizeof(abi.Primitive) == 408 and ctypes.sizeof(abi.Light) == 112 and ctypes.sizeof(abi.Camera) == 136
-    assert ctypes.sizeof(abi.SceneDesc) == 256 and ctypes.sizeof(abi.Stats) == 80
+    assert ctypes.sizeof(abi.SceneDesc) == 256 and ctypes.sizeof(abi.Stats) == 88
 
 
 def test_last_error_is_thread_local_string():

@@ -1,0 +1,88 @@
+"""GPU tests of the exchange step and of the several-GPUs-in-one-process frame call (rt_render_frame_multi).
+The box has one GPU: the N > 1 code path is exercised by naming that GPU several times (members then share it), which
+runs the same partition, pack, peer copy and unpack code as N distinct GPUs would."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+from cuda_raytracing_amd import abi
+from cuda_raytracing_amd.distributed import owned_mask, packed_index
+from cuda_raytracing_amd.host import HostScene
+from helpers import SCENES
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(name):
+    return HostScene(os.path.join(SCENES, name + ".txt"))
+
+
+@pytest.mark.parametrize("W,H,tile,world", [(100, 70, 16, 3), (64, 48, 32, 2), (33, 17, 8, 2), (1920, 1080, 32, 8), (40, 24, 32, 5)])
+def test_pack_and_unpack_kernels_match_the_packed_order(W, H, tile, world):
+    import torch
+    lib = abi.load_library()
+    abi.check(lib.rt_init(0))
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 2 ** 31, (H, W), dtype=np.int64).astype(np.int32)
+    dev = torch.from_numpy(frame).cuda()
+    rebuilt = torch.zeros_like(dev)
+    total = 0
+    for part in range(world):
+        idx = packed_index(W, H, tile, part, world)
+        n = int(lib.rt_member_pixels(W, H, tile, part, world))
+        assert n == idx.size == int(owned_mask(W, H, tile, part, world).sum())
+        total += n
+        packed = torch.full((max(n, 1),), -1, dtype=torch.int32, device="cuda")
+        abi.check(lib.rt_pack_tiles(dev.data_ptr(), W, H, tile, part, world, packed.data_ptr()))
+        torch.cuda.synchronize()
+        assert np.array_equal(packed.cpu().numpy()[:n], frame.reshape(-1)[idx])
+        abi.check(lib.rt_unpack_tiles(packed.data_ptr(), W, H, tile, part, world, rebuilt.data_ptr()))
+    torch.cuda.synchronize()
+    assert total == W * H and torch.equal(rebuilt, dev)
+
+
+@pytest.mark.parametrize("members", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_frame_of_a_scene_group_equals_the_single_scene_frame(members):
+    from cuda_raytracing_amd.device import DeviceScene, SceneGroup
+    hs = scene("t_icosa")
+    W, H = 200, 136
+    st = orc.settings(spp=3, dof=True, focal=9.0, aperture=1.0, seed=4, flags=abi.RT_MODE_GPU_REF)
+    with DeviceScene(hs, device=0) as ds:
+        ref, rstats = ds.render_frame(st, W, H)
+    with SceneGroup(hs, devices=members) as grp:
+        assert grp.size == len(members)
+        img, stats = grp.render_frame(st, W, H, tile=32)
+        again, _ = grp.render_frame(st, W, H, tile=16)
+        assert all(ms > 0 for ms in grp.member_ms)
+        import torch
+        dev = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        grp.render_frame(st, W, H, out=dev)
+    assert np.array_equal(img, ref) and np.array_equal(again, ref) and np.array_equal(dev.cpu().numpy(), ref)
+    for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_shadow_traced", "shaded_hits", "texture_fetches", "pixels"):
+        assert getattr(stats, k) == getattr(rstats, k), k
+
+
+def test_group_rejects_gpus_that_do_not_exist():
+    from cuda_raytracing_amd.device import SceneGroup
+    hs = scene("c1_purple_sphere")
+    n = abi.load_library().rt_device_count()
+    with pytest.raises(abi.RtError) as e:
+        SceneGroup(hs, devices=[0, n])
+    assert "does not exist" in str(e.value)
+
+
+def test_renderer_cli_with_a_gpu_count(tmp_path):
+    """rt_render --gpus 1 goes through the plain path; the frame must not depend on it."""
+    import subprocess
+    from helpers import ROOT
+    exe = os.path.join(ROOT, "cuda_raytracing_amd", "rt_render")
+    outs = []
+    for extra in ([], ["--gpus", "1"]):
+        out = tmp_path / f"o{len(outs)}.bmp"
+        p = subprocess.run([exe, "--scene", os.path.join(SCENES, "t_icosa.txt"), "--assets", os.path.join(ROOT, "assets"), "--out", str(out),
+                            "--size", "96x72", "--spp", "2", "--seed", "1"] + extra, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1]

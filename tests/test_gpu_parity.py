@@ -201,9 +201,9 @@ def test_trees_built_on_the_device_give_the_same_image(name, W, H, spp):
 
 
 def test_shadow_walk_variants_give_the_same_image(monkeypatch):
-    """Plain and wave-shared shadow mesh walks, and the timed choice between them, render the same bits."""
+    """Plain and wave-shared shadow mesh walks, and the library's own choice between them, render the same bits."""
     hs = scene("c5_final")
-    W, H = 400, 264  # 1650 blocks: enough for the timing samples
+    W, H = 400, 264
     st = orc.settings(spp=2, dof=True, focal=168.0, aperture=150.0, seed=5, flags=abi.RT_MODE_GPU_REF)
     images, rays = [], []
     for choice in ("0", "1", None):
@@ -213,17 +213,48 @@ def test_shadow_walk_variants_give_the_same_image(monkeypatch):
             monkeypatch.setenv("RT_AMD_SHARED_WALK", choice)
         with device_scene(hs) as ds:
             img, s = ds.render_frame(st, W, H)
-            picked, plain_ms, shared_ms = ds.shared_walk
-            if choice is None:
-                assert picked in (0, 1) and plain_ms > 0.0 and shared_ms > 0.0
-                again, _ = ds.render_frame(st, W, H)
-                assert np.array_equal(again, img)
-            else:
-                assert picked == int(choice)
+            picked, _, _ = ds.shared_walk
+            assert picked == (1 if choice is None else int(choice))  # a scene with meshes gets the shared variant
         images.append(img)
-        rays.append(s.rays)
+        rays.append((s.rays, s.rays_shadow_traced))
     assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
     assert rays[0] == rays[1] == rays[2]
+    assert 0 < rays[0][1] < s.rays_shadow
+
+
+def test_many_overlapping_meshes_shared_plain_and_strict_agree(tmp_path, monkeypatch):
+    """Seven meshes whose boxes overlap between a floor and two lamps: a shadow ray has more candidate meshes than roots fit
+    on the shared walk's stack, so some are walked by the lane on its own."""
+    rng = np.random.default_rng(3)
+    text = [EDGE_HEAD.replace("image_W= 64", "image_W= 96").replace("image_H= 48", "image_H= 72"),
+            "light sphere\n O= 1 -2 6\n R= 0.5\n color= 1 1 1\nend\n", "light point\n O= -3 -3 5\n color= 0.5 0.5 0.4\nend\n",
+            "primitive plane\n N= 0 0 1\n R= 0\n color= 1 1 1\n diff= 0.9\nend\n"]
+    for k in range(7):
+        n = 40
+        verts = rng.normal(size=(n, 3)) * 0.6
+        faces = [(1 + rng.integers(0, n), 1 + rng.integers(0, n), 1 + rng.integers(0, n)) for _ in range(60)]
+        faces = [f for f in faces if len(set(f)) == 3]
+        (tmp_path / f"m{k}.obj").write_text("".join(f"v {v[0]:.5f} {v[1]:.5f} {v[2]:.5f}\n" for v in verts) + "".join(f"f {a} {b} {c}\n" for a, b, c in faces))
+        text.append(f"primitive mesh\n O= {0.25 * k - 0.8:.2f} {0.1 * k:.2f} {1.2 + 0.15 * k:.2f}\n scale= 1 1 1\n rotation= 0.{k} 0.2 0\n file= m{k}.obj\n"
+                    f" color= 0.{3 + k} 0.6 0.{9 - k}\n diff= 0.8\n refl= 0.1\nend\n")
+    (tmp_path / "s.txt").write_text("".join(text))
+    hs = HostScene(str(tmp_path / "s.txt"), asset_dir=str(tmp_path))
+    W, H = 96, 72
+    st = orc.settings(spp=2, dof=True, focal=6.0, aperture=1.0, seed=9, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
+    ref, _, ostats = orc.render(hs, st, W, H)
+    images = []
+    for choice in ("0", "1"):
+        monkeypatch.setenv("RT_AMD_SHARED_WALK", choice)
+        with device_scene(hs) as ds:
+            if choice == "0":
+                strict, sstats = ds.render_frame(st, W, H)
+            fast, fstats = ds.render_frame(orc.settings(spp=2, dof=True, focal=6.0, aperture=1.0, seed=9, flags=abi.RT_MODE_GPU_REF), W, H)
+            assert ds.shared_walk[0] == int(choice)
+        images.append(fast)
+    assert_colour_close(strict, ref, "seven meshes")
+    assert sstats.rays == ostats.rays and sstats.nodes_visited == ostats.nodes_visited
+    assert np.array_equal(images[0], strict) and np.array_equal(images[1], strict)
+    assert fstats.rays == sstats.rays
 
 
 FLAGS = [abi.RT_F_NORMALIZE_PRIMARY, abi.RT_F_SKY_Y, abi.RT_F_TIE_LATER_WINS, abi.RT_F_SHADOW_SELF_SKIP, abi.RT_F_SQUARE_UV_NO_ORIGIN,

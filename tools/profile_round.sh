@@ -1,23 +1,24 @@
 #!/bin/bash
-# Profiles of the headline bench (run on the GPU box): kernel trace + stats, then PMC passes, each
-# in a process of its own (one counter group per pass).  Usage: tools/profile_round.sh r01
+# Profiles of one bench configuration (run on the GPU box): kernel trace + stats, then PMC passes, each in a process
+# of its own (one counter group per pass).  Usage: tools/profile_round.sh <tag> [config]      (config: headline|c1..c5)
+# Leaves gpurun_out/prof_<tag>/summary/{kernel_stats.csv, pmc_<config>.json, bench_line.json}; copy what is to be kept
+# into profiles/<tag>/ and (for the numbers bench.py reads) into profiles/current/.
 set -e
-R=${1:-r01}
+R=${1:-r02}
+CFG=${2:-headline}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-# the kernel variant is fixed so that every frame is one render launch (the timed choice would add four sample launches to the first frame)
-export RT_AMD_SHARED_WALK=${RT_AMD_SHARED_WALK:-1}
-B="python3 bench.py --no-cpu-baseline"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_write.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_sq.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_FLAT --output-format csv -d $OUT/pmc_sq2 -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_sq2.log 2>&1 || echo "pmc_sq2 pass failed (non-fatal)"
-python3 - $OUT $R <<'PY'
-# summaries worth committing: per-kernel stats and the counters of the render kernel, copied to profiles/<tag>/ by hand
+B="python3 bench.py --config $CFG --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_write.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_sq.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_FLAT --output-format csv -d $OUT/pmc_sq2 -- $B --steps 1 --warmup 0 --no-strict > $OUT/pmc_sq2.log 2>&1 || echo "pmc_sq2 pass failed (non-fatal)"
+python3 - $OUT $CFG <<'PY'
+# summaries worth committing: per-kernel stats and the counters of the render kernel (summed over the launches of the one frame)
 import csv, glob, json, os, sys
-out, tag = sys.argv[1], sys.argv[2]
+out, cfg = sys.argv[1], sys.argv[2]
 summ = {}
 for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     acc = {}
@@ -28,7 +29,7 @@ for grp in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     summ[grp] = acc
 dst = f"{out}/summary"
 os.makedirs(dst, exist_ok=True)
-json.dump(summ, open(f"{dst}/pmc_render_kernel.json", "w"), indent=1, sort_keys=True)
+json.dump(summ, open(f"{dst}/pmc_{cfg}.json", "w"), indent=1, sort_keys=True)
 for f in glob.glob(f"{out}/trace/*/*_kernel_stats.csv"):
     open(f"{dst}/kernel_stats.csv", "w").write(open(f).read())
 for line in open(f"{out}/trace.log"):
