@@ -170,6 +170,7 @@ _SIGNATURES = {
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render_tile": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p, _P(Stats)]),
     "rt_render_frame": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 7 + [C.c_void_p, _P(Stats)]),
+    "rt_render_tile_noalloc": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p, _P(Stats)]),
     "rt_device_count": (C.c_int, []),
     "rt_scene_group_create": (C.c_int, [_P(SceneDesc), C.c_int, _P(C.c_int), _P(C.c_void_p)]),
     "rt_scene_group_destroy": (None, [C.c_void_p]),

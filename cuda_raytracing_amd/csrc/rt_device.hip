@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -638,6 +639,40 @@ struct rt_scene {
     float tree_build_ms = 0.0f;  // device time of the four-wide tree build, 0 if the host built the trees
 };
 
+// ---- fixed workspace of rt_render_tile_noalloc ----------------------------------------------------
+// One array per GPU the library runs on, held until the process ends: queue heads | counters | block list | path colours.
+#define RT_NOALLOC_BLOCKS 16384u                     // 8x8 pixel blocks of one call (1 M pixels)
+#define RT_NOALLOC_PATHS (1u << 19)                  // paths of one launch; a call with more is cut into several launches
+#define RT_NOALLOC_OFF_COUNTERS 256u
+#define RT_NOALLOC_OFF_BLOCKS 1024u
+#define RT_NOALLOC_OFF_PATHS (RT_NOALLOC_OFF_BLOCKS + RT_NOALLOC_BLOCKS * 8u)
+#define RT_NOALLOC_BYTES (RT_NOALLOC_OFF_PATHS + RT_NOALLOC_PATHS * 24u)  // 12.1 MiB
+static_assert(sizeof(unsigned long long) * (CTR_ALL + 16) <= RT_NOALLOC_OFF_BLOCKS - RT_NOALLOC_OFF_COUNTERS, "counters fit their slot");
+static_assert(RT_NOALLOC_OFF_PATHS % 256 == 0 && sizeof(BlockRec) == 8, "workspace layout");
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+
+#define RT_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];  // per device: where that GPU's copy of `scratch` lives (null = not looked up yet)
+
+// Address of the current device's copy of `scratch`.  The array's name is only a handle on the host; every use of the
+// array's memory from host code (kernel arguments, memsets, copies) goes through the pointer returned here.
+static int scratch_of_device(int device, unsigned char** out) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return rt_fail(RT_ERR_LIMIT, "device index beyond RT_MAX_DEVICES");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        int cur = -1;
+        HIPCHK(hipGetDevice(&cur));
+        if (cur != device) return rt_fail(RT_ERR_INVALID, "scratch_of_device: the device is not current");
+        void* ptr = nullptr;
+        HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return rt_fail(RT_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the workspace");
+        g_scratch_ptr[device] = (unsigned char*)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 extern "C" int rt_init(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return rt_fail(RT_ERR_NOGPU, "no HIP device visible");
@@ -647,7 +682,8 @@ extern "C" int rt_init(int device) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return rt_fail(RT_ERR_NOGPU, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
-    return RT_OK;
+    unsigned char* ws = nullptr;
+    return scratch_of_device(device, &ws);  // this GPU's fixed workspace (rt_render_tile_noalloc), looked up once
 }
 
 extern "C" int rt_set_stream(void* hip_stream) {
@@ -1070,6 +1106,43 @@ extern "C" int rt_render_tile(rt_scene* s, const rt_settings* st, int tex_w, int
         return rt_fail(RT_ERR_INVALID, "rectangle does not lie inside the image");
     std::vector<Tile> tiles{Tile{x0, y0, w, h}};
     return render_common(s, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba, stats);
+}
+
+// rt_render_tile for callers that may not allocate device memory: the same kernels, with the queue heads, counters, block
+// list and path colours in this GPU's copy of `scratch` instead of buffers the scene owns and grows.  Nothing here calls
+// hipMalloc / hipFree.  The array keeps the previous call's contents: the queue heads and counters are cleared per launch,
+// the block list is rewritten, and path colours are read only where this call wrote them.  Calls that overlap on one GPU
+// (other threads, other streams, other scenes) would share the array and race.
+extern "C" int rt_render_tile_noalloc(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, int x0, int y0, int w,
+                                      int h, uint8_t* rgba_device, rt_stats* stats) {
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = check_common(s, st, tex_w, tex_h);
+    if (rc) return rc;
+    if (x0 < 0 || y0 < 0 || w <= 0 || h <= 0 || x0 + w > tex_w || y0 + h > tex_h)
+        return rt_fail(RT_ERR_INVALID, "rectangle does not lie inside the image");
+    if (!rgba_device) return rt_fail(RT_ERR_INVALID, "null output image");
+    const uint64_t n_blocks = (uint64_t)((w + 7) / 8) * (uint64_t)((h + 7) / 8);
+    if (n_blocks > RT_NOALLOC_BLOCKS)
+        return rt_fail(RT_ERR_LIMIT, "rt_render_tile_noalloc: the rectangle has " + std::to_string(n_blocks) + " blocks of 8x8 pixels, the fixed workspace holds " +
+                                         std::to_string(RT_NOALLOC_BLOCKS) + " (about 1 M pixels); render it in parts");
+    if ((uint64_t)st->spp * 64u > RT_NOALLOC_PATHS)
+        return rt_fail(RT_ERR_LIMIT, "rt_render_tile_noalloc: at most " + std::to_string(RT_NOALLOC_PATHS / 64u) + " samples per pixel fit the fixed workspace");
+    HIPCHK(hipSetDevice(s->device));
+    if (!is_device_ptr(rgba_device)) return rt_fail(RT_ERR_INVALID, "rt_render_tile_noalloc: the image must be device memory (a host image needs a staging buffer)");
+    unsigned char* base = nullptr;
+    rc = scratch_of_device(s->device, &base);
+    if (rc) return rc;
+    Workspace ws;
+    ws.fixed = true;
+    ws.queue = reinterpret_cast<uint32_t*>(base);
+    ws.counters = reinterpret_cast<unsigned long long*>(base + RT_NOALLOC_OFF_COUNTERS);
+    ws.blocks = reinterpret_cast<BlockRec*>(base + RT_NOALLOC_OFF_BLOCKS), ws.blocks_cap = RT_NOALLOC_BLOCKS;
+    ws.path_out = reinterpret_cast<double*>(base + RT_NOALLOC_OFF_PATHS), ws.path_out_bytes = (size_t)RT_NOALLOC_PATHS * 24u;
+    std::vector<Tile> tiles{Tile{x0, y0, w, h}};
+    rc = launch_tiles(s, ws, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba_device, stats);
+    if (rc) return rc;
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
 }
 
 extern "C" int rt_render_frame(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, int tile, int part,

@@ -85,6 +85,15 @@ class DeviceScene:
         abi.check(self._lib.rt_render_frame(self._h, C.byref(st), tex_w, tex_h, cw, ch, tile, part, n_parts, self._ptr(out), C.byref(stats)))
         return out, stats
 
+    def render_tile_noalloc(self, st, tex_w, tex_h, rect, out, cam=None):
+        """rt_render_tile_noalloc: like render_tile, into a device image (`out`: torch CUDA uint8 tensor), without any
+        device allocation on the library's side."""
+        x0, y0, w, h = rect
+        cw, ch = cam or (tex_w, tex_h)
+        stats = abi.Stats()
+        abi.check(self._lib.rt_render_tile_noalloc(self._h, C.byref(st), tex_w, tex_h, cw, ch, x0, y0, w, h, self._ptr(out), C.byref(stats)))
+        return out, stats
+
     def trace_primary(self, st, tex_w, tex_h, rect=None, cam=None, visit_cap=0):
         x0, y0, w, h = rect or (0, 0, tex_w, tex_h)
         cw, ch = cam or (tex_w, tex_h)

@@ -272,6 +272,19 @@ int rt_render_tile(rt_scene* scene, const rt_settings* settings, int tex_w, int 
 int rt_render_frame(rt_scene* scene, const rt_settings* settings, int tex_w, int tex_h, int cam_w,
                     int cam_h, int tile, int part, int n_parts, uint8_t* rgba, rt_stats* stats);
 
+/* rt_render_tile for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same kernels and
+ * same result as rt_render_tile, but the work buffers (queue heads, counters, the rectangle's list of
+ * 8x8 pixel blocks, the path colours of one launch) live in a fixed 12.1 MiB array in device memory
+ * that every GPU the library runs on holds until the process ends; nothing is allocated or freed by
+ * this call.  `rgba_device` must be device memory on the scene's GPU (tex_w*tex_h*4 bytes).  Limits
+ * (RT_ERR_LIMIT beyond them): the rectangle may hold at most 16384 blocks of 8x8 pixels (about 1 M
+ * pixels) and settings->spp at most 8192; calls with more than 2^19 paths run as several launches.
+ * All calls on one GPU share that GPU's array: calls that overlap in time (threads, streams, scenes)
+ * race.  Blocking, like every other call. */
+int rt_render_tile_noalloc(rt_scene* scene, const rt_settings* settings, int tex_w, int tex_h, int cam_w,
+                           int cam_h, int x0, int y0, int w, int h, uint8_t* rgba_device, rt_stats* stats);
+
 /* ---- several GPUs in one process --------------------------------------------------------------
  * launchRayTraceKernelParallel (CR/RayTracer.cuh:13, CR/RayTracer.cu:134-169) renders the whole frame
  * with one call on the one GPU the reference knows (cudaSetDevice(0), CR/Renderer.cpp:104).  A scene
