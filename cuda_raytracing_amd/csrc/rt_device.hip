@@ -502,8 +502,11 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
 // SHARE: shadow rays walk the meshes with mesh_anyhit_shared (idle lanes take over parts of long walks).  Faster where
 // such walks dominate (c5_final: 265 -> 205 ms/frame), slower elsewhere because of the registers it takes (c4_lucy:
 // 44 -> 49 ms), so the host picks the variant per scene by timing both on part of a frame.
-template <bool STRICT, int SHADE_CAP, bool SHARE>
-__global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderParams P) {
+// WAVES: resident waves per SIMD the kernel is built for (register budget 512 / WAVES).  Three is best wherever the varied
+// path code dominates (at four it spills three times as much: c4_lucy 44 -> 57 ms/frame); four pays where shadow rays
+// walking meshes dominate, because that loop waits on dependent node loads (c5_final at 32 spp: 182 -> 169 ms/frame).
+template <bool STRICT, int SHADE_CAP, bool SHARE, int WAVES = RT_WAVES_PER_SIMD>
+__global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams P) {
     const int lane = lane_id();
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
     __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
@@ -528,9 +531,10 @@ __global__ __launch_bounds__(256, RT_WAVES_PER_SIMD) void render_kernel(RenderPa
     ctr.prof = s_prof[threadIdx.x >> 6];
     if (lane < 1 + PF_COUNT) ctr.prof[lane] = lane == 0 ? __builtin_readcyclecounter() : 0ull;
 #endif
-    // flags, exchange arrays and per-ray hit records of the shared walks, 448 words per wave
-    __shared__ __attribute__((aligned(8))) uint32_t s_xch[SHARE ? 4 * 448 : 2];
-    uint32_t* xch = SHARE ? s_xch + (threadIdx.x >> 6) * 448 : nullptr;
+    // flags and exchange arrays of the shared walks (192 words per wave), plus the per-ray hit records of the shared closest-hit walk
+    constexpr int XCH_WORDS = RT_SHARE_CLOSEST ? 448 : 192;
+    __shared__ __attribute__((aligned(8))) uint32_t s_xch[SHARE ? 4 * XCH_WORDS : 2];
+    uint32_t* xch = SHARE ? s_xch + (threadIdx.x >> 6) * XCH_WORDS : nullptr;
     trace_stream<STRICT, SHARE>(P, shade, ctr, stk, xch);
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_REFILL);
@@ -631,6 +635,7 @@ struct rt_scene {
     uint8_t* image = nullptr;              // staging image for host destinations
     size_t image_bytes = 0;
     int shared_walk = 0;                   // shadow mesh walks shared by the wave (render_kernel<.., SHARE = true>): 0 = no, 1 = yes
+    int waves = RT_WAVES_PER_SIMD;         // kernel build the scene gets: RT_WAVES_PER_SIMD, or 4 for mesh-heavy scenes (shared variant only)
     size_t n_blocks = 0;                   // blocks in ws.blocks: those of last_tiles
     std::vector<Tile> last_tiles;
     int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
@@ -881,6 +886,18 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->shared_walk = (v.mesh_scale_max > 0.0 && v.n_prims <= RT_SHADE_LDS) ? 1 : 0;
     if (const char* e = std::getenv("RT_AMD_SHARED_WALK"))
         if ((e[0] == '0' || e[0] == '1') && v.n_prims <= RT_SHADE_LDS) s->shared_walk = e[0] - '0';
+    // Four waves per SIMD where shadow walks over meshes carry the frame: several meshes, or one large one (more triangles than
+    // 64 Ki).  RT_AMD_WAVES=3|4 overrides the rule.
+    {
+        int meshes = 0;
+        for (int i = 0; i < d->n_primitives; i++)
+            if (geom[i].type == RT_PRIM_MESH && geom[i].aux2) meshes++;
+        // (the four-wave build exists for the small shading table only: with the large one, four blocks do not fit a CU's LDS)
+        const bool can4 = s->shared_walk && v.n_prims <= 16;
+        s->waves = (can4 && (meshes >= 2 || d->n_leaves > 65536u)) ? 4 : RT_WAVES_PER_SIMD;
+        if (const char* e = std::getenv("RT_AMD_WAVES"))
+            if (e[0] == '3' || (e[0] == '4' && can4)) s->waves = e[0] - '0';
+    }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, s->device));
     s->cus = prop.multiProcessorCount;
@@ -960,7 +977,8 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         if (!ws.fixed) s->last_tiles = tiles, s->n_blocks = recs.size();
     }
     const bool strict = (st->flags & RT_F_STRICT_TRAVERSAL) != 0;
-    const int bpc = strict ? s->blocks_per_cu_strict : s->blocks_per_cu_fast;
+    const bool four = !strict && s->shared_walk == 1 && s->waves == 4;
+    const int bpc = strict ? s->blocks_per_cu_strict : four ? 4 : s->blocks_per_cu_fast;
     // blocks per launch: the colours of all paths of a launch are kept until its pixel sums are taken
     const uint64_t block_paths = 64ull * (uint64_t)st->spp;
     uint64_t launch_paths = RT_LAUNCH_PATHS;
@@ -1006,6 +1024,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         if (grid > want_blocks) grid = want_blocks;
         const dim3 g((unsigned)grid), t(256);
         if (strict) hipLaunchKernelGGL((render_kernel<true, 0, false>), g, t, 0, g_stream, P);
+        else if (P.sc.n_prims <= 16 && four) hipLaunchKernelGGL((render_kernel<false, 16, true, 4>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= 16 && share) hipLaunchKernelGGL((render_kernel<false, 16, true>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= 16) hipLaunchKernelGGL((render_kernel<false, 16, false>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= RT_SHADE_LDS && share) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS, true>), g, t, 0, g_stream, P);

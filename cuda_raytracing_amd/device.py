@@ -37,6 +37,10 @@ class DeviceScene:
         choice = int(self._lib.rt_scene_shared_walk(self._h, C.byref(a), C.byref(b)))
         return choice, a.value, b.value
 
+    @property
+    def waves_per_simd(self):
+        return int(self._lib.rt_scene_waves_per_simd(self._h))
+
     def close(self):
         if self._h:
             self._lib.rt_scene_destroy(self._h)

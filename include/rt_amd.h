@@ -251,6 +251,10 @@ double rt_scene_tree_build_ms(const rt_scene* scene);
  * the two times are always 0 (nothing is timed).  RT_AMD_SHARED_WALK=0|1 in the environment overrides
  * the rule.  No counterpart in the reference. */
 int rt_scene_shared_walk(const rt_scene* scene, double* plain_ms, double* shared_ms);
+/* The shared variant is built twice, for three and for four resident waves per SIMD (168 / 128 registers per lane).  Four pays
+ * only where shadow rays walking meshes carry the frame; scenes with several meshes or more than 65536 triangles get it
+ * (RT_AMD_WAVES=3|4 overrides).  Returns the build this scene's pruned renders use.  No counterpart in the reference. */
+int rt_scene_waves_per_simd(const rt_scene* scene);
 
 /* Upload a scene: one slab, one copy.  Replaces createCudaSceneFromCPUScene
  * (CR/Renderer_CUDA.cpp:298-335). */
