@@ -1,0 +1,174 @@
+"""Randomised scenes against the shortcuts of the pruned render: candidate masks per lamp, umbra tests, bounding capsules,
+the candidate grid, the four-wide walk with its single-precision boxes, the shared shadow walk.  Every one of them must
+be invisible: the pruned image equals the reference-order image bit for bit and the ray totals are the same.  A sample of
+the scenes is also checked against the CPU oracle, so that "both GPU modes wrong in the same way" cannot pass.
+
+The generator aims at what the shortcuts are made of: lamps of all three kinds, some inside or right behind objects;
+spheres and cylinders large enough to put whole regions into their umbra; huge wall spheres around the scene;
+axis-parallel squares and planes; thin long cylinders and Bezier stacks (capsule tests); small meshes, several at once."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as orc
+from cuda_raytracing_amd import abi
+from cuda_raytracing_amd.host import HostScene
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+N_SCENES = 400
+W, H, SPP = 64, 48, 2
+
+
+def _v(a):
+    return " ".join(f"{x:.4f}" for x in a)
+
+
+def _material(rng, allow_glass=True):
+    kind = rng.integers(0, 5 if allow_glass else 3)
+    c = 0.2 + 0.8 * rng.random(3)
+    lines = [f" color= {_v(c)}"]
+    if kind == 0:
+        lines += [f" diff= {0.5 + 0.5 * rng.random():.3f}"]
+    elif kind == 1:
+        lines += [f" diff= {0.3 + 0.5 * rng.random():.3f}", f" spec= {0.5 * rng.random():.3f}", f" refl= {0.4 * rng.random():.3f}"]
+        if rng.random() < 0.3:
+            lines += [f" drefl= {0.2 * rng.random():.3f}"]
+    elif kind == 2:
+        lines += [f" refl= {0.4 + 0.5 * rng.random():.3f}", f" diff= {0.3 * rng.random():.3f}"]
+    elif kind == 3:
+        lines += [f" refr= {0.6 + 0.4 * rng.random():.3f}", f" rindex= {1.2 + 0.6 * rng.random():.3f}", f" absor= {_v(rng.random(3))}"]
+    else:
+        lines += [f" refr= {0.5 + 0.4 * rng.random():.3f}", f" refl= {0.3 * rng.random():.3f}", f" rindex= {1.3 + 0.5 * rng.random():.3f}",
+                  f" diff= {0.3 * rng.random():.3f}"]
+    return "\n".join(lines) + "\n"
+
+
+def make_scene(seed, tmp):
+    rng = np.random.default_rng(seed)
+    sq = [0.25, 0.5, 1.0][rng.integers(0, 3)]
+    t = [f"background\n top= {_v(rng.random(3))}\n bottom= {_v(rng.random(3))}\nend\n",
+         f"camera\n O= {_v([rng.normal(0, 1), -9 + rng.normal(0, 1), 2.5 + rng.normal(0, 0.7)])}\n N= {_v([rng.normal(0, 0.1), 1, -0.2 + rng.normal(0, 0.1)])}\n"
+         f" lens_W= 1.0\n lens_H= 0.75\n image_W= {W}\n image_H= {H}\n shade_quality= {sq}\n drefl_quality= 1\nend\n"]
+    centres = []  # where objects are, so that some lamps can go inside / right behind them
+    n_obj = rng.integers(2, 9)
+    floor = rng.integers(0, 3)
+    if floor == 0:
+        t.append(f"primitive plane\n N= 0 0 1\n R= 0\n Dx= 3 0 0\n Dy= 0 3 0\n{_material(rng, False)}" + (" texture= floor.bmp\n" if rng.random() < 0.5 else "") + "end\n")
+    elif floor == 1:
+        t.append(f"primitive square\n O= 0 0 0\n Dx= {6 + 4 * rng.random():.3f} 0 0\n Dy= 0 {6 + 4 * rng.random():.3f} 0\n{_material(rng, False)}end\n")
+    if rng.random() < 0.3:  # walls: spheres so large that the scene sits inside them, or a huge one beside it
+        r = 10.0 ** rng.uniform(2, 5)
+        where = [0, 0, r - 0.5 - 8 * rng.random()] if rng.random() < 0.5 else [r + 6, 0, 0]
+        t.append(f"primitive sphere\n O= {_v(where)}\n R= {r:.3f}\n{_material(rng, False)}end\n")
+    if rng.random() < 0.25:
+        axis = rng.integers(0, 3)
+        o = [0.0, 0.0, 0.0]
+        o[axis] = 5.0 + rng.random()
+        dx, dy = [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]
+        dx[(axis + 1) % 3], dy[(axis + 2) % 3] = 4.0, 4.0
+        t.append(f"primitive square\n O= {_v(o)}\n Dx= {_v(dx)}\n Dy= {_v(dy)}\n{_material(rng)}end\n")
+    for _ in range(n_obj):
+        c = np.array([rng.normal(0, 2.2), rng.normal(0, 2.2), abs(rng.normal(1.5, 1.2))])
+        centres.append(c)
+        k = rng.integers(0, 8)
+        if k <= 1:
+            r = [0.3, 0.8, 1.6, 3.0][rng.integers(0, 4)] * (0.7 + 0.6 * rng.random())
+            t.append(f"primitive sphere\n O= {_v(c)}\n R= {r:.4f}\n{_material(rng)}end\n")
+        elif k == 2:
+            ax = rng.normal(size=3) if rng.random() < 0.6 else np.eye(3)[rng.integers(0, 3)]
+            ax = ax / np.linalg.norm(ax) * (0.5 + 4 * rng.random())
+            r = [0.08, 0.4, 1.5][rng.integers(0, 3)] * (0.7 + 0.6 * rng.random())
+            t.append(f"primitive cylinder\n O1= {_v(c)}\n O2= {_v(c + ax)}\n R= {r:.4f}\n{_material(rng)}" + (" texture= marble.bmp\n" if rng.random() < 0.3 else "") + "end\n")
+        elif k == 3:
+            ax = np.array([0, 0, 1.0]) if rng.random() < 0.5 else rng.normal(size=3)
+            ax = ax / np.linalg.norm(ax) * (1 + 2 * rng.random())
+            pts = "".join(f" P= {z:.3f} {r:.3f}\n" for z, r in zip(np.sort(rng.random(rng.integers(3, 7))) * 2.5, 0.2 + rng.random(7)))
+            t.append(f"primitive bezier\n O1= {_v(c)}\n O2= {_v(c + ax)}\n{pts}{_material(rng, False)}end\n")
+        elif k == 4:
+            a, b = rng.normal(0, 1.2, 3), rng.normal(0, 1.2, 3)
+            t.append(f"primitive triangle\n O1= {_v(c)}\n O2= {_v(c + a)}\n O3= {_v(c + b)}\n{_material(rng, False)}end\n")
+        elif k == 5:
+            a = rng.normal(size=3)
+            b = np.cross(a, rng.normal(size=3))
+            a, b = a / np.linalg.norm(a) * (0.5 + 2 * rng.random()), b / np.linalg.norm(b) * (0.5 + 2 * rng.random())
+            t.append(f"primitive square\n O= {_v(c)}\n Dx= {_v(a)}\n Dy= {_v(b)}\n{_material(rng)}end\n")
+        else:
+            f = ["icosa.obj", "boxgrid.obj"][rng.integers(0, 2)]
+            rot = rng.normal(0, 0.8, 3) if rng.random() < 0.7 else np.zeros(3)
+            s = 0.4 + 1.4 * rng.random()
+            t.append(f"primitive mesh\n O= {_v(c)}\n scale= {s:.3f} {s:.3f} {s:.3f}\n rotation= {_v(rot)}\n file= {f}\n{_material(rng)}end\n")
+    for _ in range(rng.integers(1, 4)):
+        mode = rng.integers(0, 4)
+        if mode == 0 and centres:      # inside or at an object
+            o = centres[rng.integers(0, len(centres))] + rng.normal(0, 0.2, 3)
+        elif mode == 1 and centres:    # right behind an object, seen from the origin
+            c = centres[rng.integers(0, len(centres))]
+            o = c * (1.3 + rng.random()) + np.array([0, 0, 0.5])
+        else:
+            o = np.array([rng.normal(0, 4), rng.normal(0, 4), 3 + 6 * rng.random()])
+        kind = rng.integers(0, 3)
+        col = 0.3 + 1.2 * rng.random(3)
+        if kind == 0:
+            t.append(f"light point\n O= {_v(o)}\n color= {_v(col)}\nend\n")
+        elif kind == 1:
+            t.append(f"light sphere\n O= {_v(o)}\n R= {[0.05, 0.5, 1.5][rng.integers(0, 3)]:.3f}\n color= {_v(col)}\nend\n")
+        else:
+            e = 0.2 + 1.5 * rng.random()
+            t.append(f"light square\n O= {_v(o)}\n Dx= {e:.3f} 0 0\n Dy= 0 {e * (0.5 + rng.random()):.3f} 0\n color= {_v(col)}\nend\n")
+    path = os.path.join(tmp, f"fuzz_{seed}.txt")
+    with open(path, "w") as f:
+        f.write("".join(t))
+    return path
+
+
+def _keep(path, seed, why):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(path) as f, open(os.path.join(out, f"fuzz_fail_{seed}.txt"), "w") as g:
+        g.write(f"# {why}\n" + f.read())
+
+
+def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
+    from cuda_raytracing_amd.device import DeviceScene
+    failures = []
+    checked_oracle = 0
+    for seed in range(N_SCENES):
+        path = make_scene(seed, str(tmp_path))
+        hs = HostScene(path, asset_dir=os.path.join(ROOT, "assets"))
+        flags = abi.RT_MODE_GPU_REF if seed % 3 else abi.RT_MODE_CPU_REF
+        if seed % 5 == 0:
+            flags &= ~abi.RT_F_BEZIER_STACKED
+        if seed % 7 == 0:
+            flags ^= abi.RT_F_MESH_RAW_DIR
+        st = orc.settings(spp=SPP, dof=bool(seed % 2), focal=9.0, aperture=1.0, seed=seed + 1, flags=flags | abi.RT_F_STRICT_TRAVERSAL)
+        with DeviceScene(hs, device=0) as ds:
+            strict, ss = ds.render_frame(st, W, H)
+            st.flags = flags
+            fast, fs = ds.render_frame(st, W, H)
+        why = None
+        if not np.array_equal(fast, strict):
+            bad = np.argwhere((fast != strict).any(-1))
+            why = f"pruned image differs from the reference-order image at {len(bad)} pixels, first {bad[0].tolist()}"
+        else:
+            for k in ("rays_primary", "rays_secondary", "rays_shadow", "shaded_hits", "texture_fetches", "pixels"):
+                if getattr(fs, k) != getattr(ss, k):
+                    why = f"{k}: pruned {getattr(fs, k)} != reference-order {getattr(ss, k)}"
+            if fs.rays_shadow_traced > fs.rays_shadow or ss.rays_shadow_traced != ss.rays_shadow:
+                why = "traced shadow rays inconsistent"
+        if why is None and seed % 12 == 0:  # the oracle on a sample: both GPU modes could be wrong together
+            st.flags = flags | abi.RT_F_STRICT_TRAVERSAL
+            ref, _, os_ = orc.render(hs, st, W, H)
+            d = np.abs(strict[..., :3].astype(int) - ref[..., :3].astype(int))
+            if d.max() > 1 or (d.max(-1) > 0).mean() > 0.01:
+                why = f"reference-order image differs from the oracle: max {d.max()} levels, {(d.max(-1) > 0).mean():.3%} of pixels"
+            elif ss.rays != os_.rays or ss.nodes_visited != os_.nodes_visited or ss.tris_tested != os_.tris_tested:
+                why = f"counters differ from the oracle: rays {ss.rays} vs {os_.rays}, nodes {ss.nodes_visited} vs {os_.nodes_visited}"
+            checked_oracle += 1
+        if why:
+            _keep(path, seed, why)
+            failures.append((seed, why))
+    assert not failures, f"{len(failures)} of {N_SCENES} scenes failed (scene files kept in gpurun_out/fuzz_fail_<seed>.txt): {failures[:5]}"
+    assert checked_oracle >= N_SCENES // 12
