@@ -150,35 +150,25 @@ int load_texture(rt_host_scene& hs, const std::string& file) {
 }
 
 // ---- mesh files --------------------------------------------------------------------------
-// Vertex transform of CR/primitive.cpp:390-442: rotate about X, then Y, then Z, scale, translate.
+// Vertex transform of a mesh (what CR/primitive.cpp:390-442 does to every vertex): three plane rotations, about X, Y
+// and Z in that order, then the scale, then the offset.  The rotation about axis k turns the coordinate pair (k+1, k+2)
+// (indices mod 3), so one loop covers all three.  The products and sums per vertex are the reference's, one rounding
+// each: the per-mesh tree (and its hash in the tests) depends on the last bit of every coordinate, which is why the
+// rotations are not merged into one matrix.
 struct Xform {
-    double cx, sx, cy, sy, cz, sz;
-    V3 scale, O;
-    Xform(const V3& rot, const V3& s, const V3& o) : scale(s), O(o) {
-        cx = std::cos(rot.x), sx = std::sin(rot.x);
-        cy = std::cos(rot.y), sy = std::sin(rot.y);
-        cz = std::cos(rot.z), sz = std::sin(rot.z);
+    double c[3], s[3], k[3], t[3];  // per axis: cosine and sine of the rotation about it, scale, offset
+    Xform(const V3& rot, const V3& scale, const V3& o) {
+        for (int a = 0; a < 3; a++) c[a] = std::cos(rot[a]), s[a] = std::sin(rot[a]), k[a] = scale[a], t[a] = o[a];
     }
-    V3 apply(V3 v) const {
-        double y_new = cx * v.y - sx * v.z;
-        double z_new = sx * v.y + cx * v.z;
-        v.y = y_new;
-        v.z = z_new;
-        double x_new = cy * v.x + sy * v.z;
-        z_new = -sy * v.x + cy * v.z;
-        v.x = x_new;
-        v.z = z_new;
-        x_new = cz * v.x - sz * v.y;
-        y_new = sz * v.x + cz * v.y;
-        v.x = x_new;
-        v.y = y_new;
-        v.x *= scale.x;
-        v.y *= scale.y;
-        v.z *= scale.z;
-        v.x += O.x;
-        v.y += O.y;
-        v.z += O.z;
-        return v;
+    V3 apply(const V3& v) const {
+        double p[3] = {v.x, v.y, v.z};
+        for (int a = 0; a < 3; a++) {
+            const int i = (a + 1) % 3, j = (a + 2) % 3;
+            const double pi = c[a] * p[i] - s[a] * p[j], pj = s[a] * p[i] + c[a] * p[j];
+            p[i] = pi, p[j] = pj;
+        }
+        for (int a = 0; a < 3; a++) p[a] = p[a] * k[a] + t[a];
+        return V3(p[0], p[1], p[2]);
     }
 };
 
@@ -389,102 +379,114 @@ int add_mesh(rt_host_scene& hs, const HostMesh& hm) {
     return (int)hs.meshes.size() - 1;
 }
 
-// ---- key handlers ------------------------------------------------------------------------
-void material_input(rt_host_scene& hs, rt_material& m, const std::string& var, std::stringstream& fin) {
-    if (var == "color=") fin >> m.color.x >> m.color.y >> m.color.z;
-    if (var == "absor=") fin >> m.absor.x >> m.absor.y >> m.absor.z;
-    if (var == "refl=") fin >> m.refl;
-    if (var == "refr=") fin >> m.refr;
-    if (var == "diff=") fin >> m.diff;
-    if (var == "spec=") fin >> m.spec;
-    if (var == "drefl=") fin >> m.drefl;
-    if (var == "rindex=") fin >> m.rindex;
-    if (var == "texture=") {
+// ---- keys of a block ---------------------------------------------------------------------
+// A block is a list of "key= values" lines.  Which keys a block understands is a table: key -> the field it fills
+// (a number, a vector, a whole number); keys with an effect beyond storing a value have a hook.  Keys a block does not know
+// are skipped, as in the reference (a chain of string comparisons per class: CR/primitive.cpp:51-70,101-107,151-157,
+// 185-190,237-242,260-281,316-332,344-365, CR/Light.cpp:16-25,47-52,101-105, CR/camera.cpp:61-77).
+template <class T>
+struct Key {
+    const char* name;
+    double T::*num;
+    V3 T::*vec;
+    int T::*whole;
+};
+template <class T, size_t N>
+bool read_key(T& obj, const Key<T> (&keys)[N], const std::string& name, std::stringstream& in) {
+    for (const Key<T>& k : keys) {
+        if (name != k.name) continue;
+        if (k.num) in >> obj.*(k.num);
+        else if (k.vec) read_v3(in, obj.*(k.vec));
+        else if (k.whole) in >> obj.*(k.whole);
+        return true;
+    }
+    return false;
+}
+#define NUM(T, key, field) {key, &T::field, nullptr, nullptr}
+#define VEC(T, key, field) {key, nullptr, &T::field, nullptr}
+#define INT(T, key, field) {key, nullptr, nullptr, &T::field}
+
+// material keys are the same for every primitive; they fill the POD record directly
+struct MatKey {
+    const char* name;
+    double rt_material::*num;
+    rt_vec3 rt_material::*vec;
+};
+const MatKey kMaterialKeys[] = {{"color=", nullptr, &rt_material::color}, {"absor=", nullptr, &rt_material::absor}, {"refl=", &rt_material::refl, nullptr},
+                                {"refr=", &rt_material::refr, nullptr},   {"diff=", &rt_material::diff, nullptr},   {"spec=", &rt_material::spec, nullptr},
+                                {"drefl=", &rt_material::drefl, nullptr}, {"rindex=", &rt_material::rindex, nullptr}};
+void read_material_key(rt_host_scene& hs, rt_material& m, const std::string& name, std::stringstream& in) {
+    if (name == "texture=") {
         std::string file;
-        fin >> file;
+        in >> file;
         m.texture = load_texture(hs, file);
+        return;
+    }
+    for (const MatKey& k : kMaterialKeys) {
+        if (name != k.name) continue;
+        if (k.num) in >> m.*(k.num);
+        else in >> (m.*(k.vec)).x >> (m.*(k.vec)).y >> (m.*(k.vec)).z;
+        return;
     }
 }
 
+const Key<HostPrim> kSphereKeys[] = {VEC(HostPrim, "O=", O), NUM(HostPrim, "R=", R), VEC(HostPrim, "De=", De), VEC(HostPrim, "Dc=", Dc)};
+const Key<HostPrim> kPlaneKeys[] = {VEC(HostPrim, "N=", N), NUM(HostPrim, "R=", R), VEC(HostPrim, "Dx=", Dx), VEC(HostPrim, "Dy=", Dy)};
+const Key<HostPrim> kSquareKeys[] = {VEC(HostPrim, "O=", O), VEC(HostPrim, "Dx=", Dx), VEC(HostPrim, "Dy=", Dy)};
+const Key<HostPrim> kCylinderKeys[] = {VEC(HostPrim, "O1=", O1), VEC(HostPrim, "O2=", O2), NUM(HostPrim, "R=", R)};
+const Key<HostPrim> kBezierKeys[] = {VEC(HostPrim, "O1=", O1), VEC(HostPrim, "O2=", O2)};
+const Key<HostPrim> kTriangleKeys[] = {VEC(HostPrim, "O1=", O1), VEC(HostPrim, "O2=", O2), VEC(HostPrim, "O3=", O3)};
+const Key<HostPrim> kMeshKeys[] = {VEC(HostPrim, "O=", O), VEC(HostPrim, "rotation=", rotation), VEC(HostPrim, "scale=", scale)};
+const Key<HostLight> kPointLightKeys[] = {VEC(HostLight, "O=", O), VEC(HostLight, "color=", color)};
+const Key<HostLight> kSquareLightKeys[] = {VEC(HostLight, "O=", O), VEC(HostLight, "Dx=", Dx), VEC(HostLight, "Dy=", Dy), VEC(HostLight, "color=", color)};
+const Key<HostLight> kSphereLightKeys[] = {VEC(HostLight, "O=", O), NUM(HostLight, "R=", R), VEC(HostLight, "color=", color)};
+
+// One line of a primitive block.  Hooks: a Bezier's axis frame is made when its far end is read and every "P=" adds a
+// control point (CR/primitive.cpp:260-281); a triangle's normal is made when its third corner is read (:316-332); a
+// mesh is loaded when its file is named, with the offset / rotation / scale read so far (:344-365), so those keys must
+// come before "file=".
 bool primitive_input(rt_host_scene& hs, HostPrim& p, const std::string& var, std::stringstream& fin, std::string& err) {
     switch (p.type) {
-        case RT_PRIM_SPHERE:
-            if (var == "O=") read_v3(fin, p.O);
-            if (var == "R=") fin >> p.R;
-            if (var == "De=") read_v3(fin, p.De);
-            if (var == "Dc=") read_v3(fin, p.Dc);
-            break;
-        case RT_PRIM_PLANE:
-            if (var == "N=") read_v3(fin, p.N);
-            if (var == "R=") fin >> p.R;
-            if (var == "Dx=") read_v3(fin, p.Dx);
-            if (var == "Dy=") read_v3(fin, p.Dy);
-            break;
-        case RT_PRIM_SQUARE:
-            if (var == "O=") read_v3(fin, p.O);
-            if (var == "Dx=") read_v3(fin, p.Dx);
-            if (var == "Dy=") read_v3(fin, p.Dy);
-            break;
-        case RT_PRIM_CYLINDER:
-            if (var == "O1=") read_v3(fin, p.O1);
-            if (var == "O2=") read_v3(fin, p.O2);
-            if (var == "R=") fin >> p.R;
-            break;
+        case RT_PRIM_SPHERE: read_key(p, kSphereKeys, var, fin); break;
+        case RT_PRIM_PLANE: read_key(p, kPlaneKeys, var, fin); break;
+        case RT_PRIM_SQUARE: read_key(p, kSquareKeys, var, fin); break;
+        case RT_PRIM_CYLINDER: read_key(p, kCylinderKeys, var, fin); break;
         case RT_PRIM_BEZIER:
-            if (var == "O1=") read_v3(fin, p.O1);
-            if (var == "O2=") {
-                read_v3(fin, p.O2);
-                p.N = unit(p.O2 - p.O1);
-                p.Nx = vertical(p.N);
-                p.Ny = cross(p.N, p.Nx);
-            }
-            if (var == "P=") {
+            if (read_key(p, kBezierKeys, var, fin)) {
+                if (var == "O2=") p.N = unit(p.O2 - p.O1), p.Nx = vertical(p.N), p.Ny = cross(p.N, p.Nx);
+            } else if (var == "P=") {
+                double z = 0, r = 0;
+                fin >> z >> r;
                 p.degree++;
-                double newR = 0, newZ = 0;
-                fin >> newZ >> newR;
-                if (newR > p.R_c) p.R_c = newR;
-                p.bzR.push_back(newR);
-                p.bzZ.push_back(newZ);
+                p.R_c = std::max(p.R_c, r);
+                p.bzZ.push_back(z), p.bzR.push_back(r);
             }
             break;
         case RT_PRIM_TRIANGLE:
-            if (var == "O1=") read_v3(fin, p.O1);
-            if (var == "O2=") read_v3(fin, p.O2);
-            if (var == "O3=") {
-                read_v3(fin, p.O3);
-                p.N = unit(cross(p.O2 - p.O1, p.O3 - p.O1));
-            }
+            if (read_key(p, kTriangleKeys, var, fin) && var == "O3=") p.N = unit(cross(p.O2 - p.O1, p.O3 - p.O1));
             break;
         case RT_PRIM_MESH:
-            if (var == "O=") read_v3(fin, p.O);
-            if (var == "rotation=") read_v3(fin, p.rotation);
-            if (var == "scale=") read_v3(fin, p.scale);
-            if (var == "file=") {
+            if (!read_key(p, kMeshKeys, var, fin) && var == "file=") {
                 std::string file;
                 fin >> file;
-                std::string path = resolve(hs, file);
+                const std::string path = resolve(hs, file);
+                const bool packed = path.size() > 4 && path.compare(path.size() - 4, 4, ".rtm") == 0;
+                const Xform xf(p.rotation, p.scale, p.O);
                 HostMesh hm;
-                Xform xf(p.rotation, p.scale, p.O);
-                bool packed = path.size() > 4 && path.compare(path.size() - 4, 4, ".rtm") == 0;
                 if (!(packed ? load_rtm(path, xf, hm, err) : load_obj(path, xf, hm, err))) return false;
                 p.mesh = add_mesh(hs, hm);
             }
             break;
-        default:
-            break;
+        default: break;
     }
-    material_input(hs, p.mat, var, fin);
+    read_material_key(hs, p.mat, var, fin);
     return true;
 }
 
 void light_input(HostLight& l, const std::string& var, std::stringstream& fin) {
-    if (var == "O=") read_v3(fin, l.O);
-    if (l.type == RT_LIGHT_SQUARE) {
-        if (var == "Dx=") read_v3(fin, l.Dx);
-        if (var == "Dy=") read_v3(fin, l.Dy);
-    }
-    if (l.type == RT_LIGHT_SPHERE && var == "R=") fin >> l.R;
-    if (var == "color=") read_v3(fin, l.color);
+    if (l.type == RT_LIGHT_POINT) read_key(l, kPointLightKeys, var, fin);
+    else if (l.type == RT_LIGHT_SQUARE) read_key(l, kSquareLightKeys, var, fin);
+    else if (l.type == RT_LIGHT_SPHERE) read_key(l, kSphereLightKeys, var, fin);
 }
 
 struct HostCamera {
@@ -492,19 +494,7 @@ struct HostCamera {
     double lens_W = 0.88, lens_H = 0.88;
     int W = 420, H = 420;
     double shade_quality = 4, drefl_quality = 4;
-    void input(const std::string& var, std::stringstream& fin) {
-        if (var == "O=") read_v3(fin, O);
-        if (var == "N=") {
-            read_v3(fin, N);
-            N = unit(N);
-        }
-        if (var == "lens_W=") fin >> lens_W;
-        if (var == "lens_H=") fin >> lens_H;
-        if (var == "image_W=") fin >> W;
-        if (var == "image_H=") fin >> H;
-        if (var == "shade_quality=") fin >> shade_quality;
-        if (var == "drefl_quality=") fin >> drefl_quality;
-    }
+    void input(const std::string& var, std::stringstream& fin);
     void initialize() {
         N = unit(N);
         Dx = vertical(N);
@@ -513,6 +503,69 @@ struct HostCamera {
         Dy = Dy * lens_H / 2;
     }
 };
+
+const Key<HostCamera> kCameraKeys[] = {VEC(HostCamera, "O=", O), VEC(HostCamera, "N=", N), NUM(HostCamera, "lens_W=", lens_W),
+                                      NUM(HostCamera, "lens_H=", lens_H), INT(HostCamera, "image_W=", W), INT(HostCamera, "image_H=", H),
+                                      NUM(HostCamera, "shade_quality=", shade_quality), NUM(HostCamera, "drefl_quality=", drefl_quality)};
+void HostCamera::input(const std::string& var, std::stringstream& fin) {
+    if (read_key(*this, kCameraKeys, var, fin) && var == "N=") N = unit(N);  // CR/camera.cpp:63-66
+}
+
+// ---- blocks of a scene file (CR/raytracer.cpp:203-271) ----------------------------------------------
+// A file is a sequence of blocks "<kind> [<type>] ... end".  Words between blocks are read one at a time: a word that
+// starts with '#' is dropped (that one word only, so a comment containing the word "camera" opens a camera block, as in
+// the reference), any other word that is not a block kind is dropped too.  The rest of the header line (up to 1024
+// characters) is skipped; then every line is "key= values" until a line whose first word is "end".  A primitive or
+// light of a type the loader does not know still has its block consumed.
+struct Name {
+    const char* word;
+    int id;
+};
+enum { BLOCK_BACKGROUND, BLOCK_CAMERA, BLOCK_PRIMITIVE, BLOCK_LIGHT };
+const Name kBlockKinds[] = {{"background", BLOCK_BACKGROUND}, {"camera", BLOCK_CAMERA}, {"primitive", BLOCK_PRIMITIVE}, {"light", BLOCK_LIGHT}};
+const Name kPrimitiveTypes[] = {{"sphere", RT_PRIM_SPHERE},     {"plane", RT_PRIM_PLANE},   {"square", RT_PRIM_SQUARE}, {"cylinder", RT_PRIM_CYLINDER},
+                                {"bezier", RT_PRIM_BEZIER},     {"triangle", RT_PRIM_TRIANGLE}, {"mesh", RT_PRIM_MESH}};
+const Name kLightTypes[] = {{"point", RT_LIGHT_POINT}, {"square", RT_LIGHT_SQUARE}, {"sphere", RT_LIGHT_SPHERE}};
+template <size_t N>
+int find_name(const Name (&table)[N], const std::string& word) {
+    for (const Name& n : table)
+        if (word == n.word) return n.id;
+    return -1;
+}
+struct BlockHeader {
+    int kind = -1;
+    int type = -1;  // primitive / light type, -1 if the block has none or the type is unknown
+};
+bool next_block(std::istream& in, BlockHeader& h) {
+    std::string word;
+    while (in >> word) {
+        if (word[0] == '#') continue;
+        h.kind = find_name(kBlockKinds, word);
+        if (h.kind < 0) continue;
+        h.type = -1;
+        if (h.kind == BLOCK_PRIMITIVE || h.kind == BLOCK_LIGHT) {
+            std::string type;
+            in >> type;
+            h.type = h.kind == BLOCK_PRIMITIVE ? find_name(kPrimitiveTypes, type) : find_name(kLightTypes, type);
+        }
+        in.ignore(1024, '\n');
+        return true;
+    }
+    return false;
+}
+// fn(key, rest of the line) for every line of the block; fn returns false to stop reading
+template <class F>
+void each_key(std::istream& in, F fn) {
+    std::string line;
+    while (std::getline(in, line, '\n')) {
+        std::stringstream rest(line);
+        std::string key;
+        rest >> key;
+        if (!key.empty() && key[0] == '#') continue;
+        if (key == "end") break;
+        if (!fn(key, rest)) break;
+    }
+}
 
 rt_primitive to_pod(const HostPrim& p, std::string& err) {
     rt_primitive q;
@@ -586,70 +639,38 @@ extern "C" int rt_host_scene_load(const char* scene_path, const char* asset_dir,
     std::vector<HostLight> lights;  // file order
     std::string err;
 
-    // Token loop of CR/raytracer.cpp:203-271.  A '#' skips one token only, so a comment that
-    // contains a block keyword opens that block; unknown primitive / light types still
-    // consume their block.
-    std::string obj;
-    while (fin >> obj) {
-        if (obj[0] == '#') continue;
-        HostPrim* new_primitive = nullptr;
-        HostLight* new_light = nullptr;
-        if (obj == "primitive") {
-            std::string type;
-            fin >> type;
-            int t = -1;
-            if (type == "sphere") t = RT_PRIM_SPHERE;
-            if (type == "plane") t = RT_PRIM_PLANE;
-            if (type == "square") t = RT_PRIM_SQUARE;
-            if (type == "cylinder") t = RT_PRIM_CYLINDER;
-            if (type == "bezier") t = RT_PRIM_BEZIER;
-            if (type == "triangle") t = RT_PRIM_TRIANGLE;
-            if (type == "mesh") t = RT_PRIM_MESH;
-            if (t >= 0) {
-                prims.emplace_back();
-                prims.back().type = t;
-                new_primitive = &prims.back();
-            }
-        } else if (obj == "light") {
-            std::string type;
-            fin >> type;
-            int t = -1;
-            if (type == "point") t = RT_LIGHT_POINT;
-            if (type == "square") t = RT_LIGHT_SQUARE;
-            if (type == "sphere") t = RT_LIGHT_SPHERE;
-            if (t >= 0) {
-                lights.emplace_back();
-                lights.back().type = t;
-                new_light = &lights.back();
-            }
-        } else if (obj != "background" && obj != "camera")
-            continue;
-
-        fin.ignore(1024, '\n');
-        std::string order;
-        while (std::getline(fin, order, '\n')) {
-            std::stringstream fin2(order);
-            std::string var;
-            fin2 >> var;
-            if (!var.empty() && var[0] == '#') continue;
-            if (var == "end") break;
-            if (obj == "background") {
-                if (var == "color=") {
-                    read_v3(fin2, bg_top);
-                    bg_bottom = bg_top;
-                } else if (var == "top=") {
-                    read_v3(fin2, bg_top);
-                    bg_bottom = V3(1.0, 1.0, 1.0);
-                } else if (var == "bottom=") {
-                    read_v3(fin2, bg_bottom);
-                }
-            }
-            if (obj == "primitive" && new_primitive) {
-                if (!primitive_input(*hs, *new_primitive, var, fin2, err)) return rt_fail(RT_ERR_IO, err);
-            }
-            if (obj == "light" && new_light) light_input(*new_light, var, fin2);
-            if (obj == "camera") cam.input(var, fin2);
+    BlockHeader block;
+    while (next_block(fin, block)) {
+        HostPrim* prim = nullptr;
+        HostLight* light = nullptr;
+        if (block.kind == BLOCK_PRIMITIVE && block.type >= 0) {
+            prims.emplace_back();
+            prims.back().type = block.type;
+            prim = &prims.back();
+        } else if (block.kind == BLOCK_LIGHT && block.type >= 0) {
+            lights.emplace_back();
+            lights.back().type = block.type;
+            light = &lights.back();
         }
+        bool ok = true;
+        each_key(fin, [&](const std::string& key, std::stringstream& values) {
+            switch (block.kind) {
+                case BLOCK_BACKGROUND:  // CR/raytracer.cpp:240-254: one colour, or a gradient whose bottom defaults to white
+                    if (key == "color=") read_v3(values, bg_top), bg_bottom = bg_top;
+                    else if (key == "top=") read_v3(values, bg_top), bg_bottom = V3(1.0, 1.0, 1.0);
+                    else if (key == "bottom=") read_v3(values, bg_bottom);
+                    break;
+                case BLOCK_CAMERA: cam.input(key, values); break;
+                case BLOCK_PRIMITIVE:
+                    if (prim) ok = primitive_input(*hs, *prim, key, values, err);
+                    break;
+                case BLOCK_LIGHT:
+                    if (light) light_input(*light, key, values);
+                    break;
+            }
+            return ok;
+        });
+        if (!ok) return rt_fail(RT_ERR_IO, err);
     }
     cam.initialize();
 
@@ -726,7 +747,12 @@ extern "C" void rt_host_scene_free(rt_host_scene* hs) { delete hs; }
 
 extern "C" int rt_bmp_save_rgba(const char* path, const uint8_t* rgba, int width, int height) {
     if (!path || !rgba || width <= 0 || height <= 0) return rt_fail(RT_ERR_INVALID, "rt_bmp_save_rgba: bad argument");
-    uint32_t data = (uint32_t)width * (uint32_t)height * 3u;
+    // Rows are padded to a multiple of four bytes, as the format requires and as this library's own reader expects
+    // (CR/BmpSave.cpp:5-44 writes them unpadded, which only is a valid file when width * 3 is a multiple of four; for such
+    // widths - every size the reference uses - the two writers produce the same bytes).
+    const size_t row = ((size_t)width * 3 + 3) & ~(size_t)3, bytes = row * (size_t)height;
+    if (bytes + 54 > 0xFFFFFFFFull) return rt_fail(RT_ERR_LIMIT, "rt_bmp_save_rgba: image too large for a BMP file");
+    const uint32_t data = (uint32_t)bytes;
     unsigned char hdr[54];
     std::memset(hdr, 0, sizeof(hdr));
     auto p32 = [&](int o, uint32_t v) { hdr[o] = v & 255, hdr[o + 1] = (v >> 8) & 255, hdr[o + 2] = (v >> 16) & 255, hdr[o + 3] = (v >> 24) & 255; };
@@ -739,12 +765,13 @@ extern "C" int rt_bmp_save_rgba(const char* path, const uint8_t* rgba, int width
     hdr[26] = 1;
     hdr[28] = 24;
     p32(34, data);
-    std::vector<uint8_t> bgr((size_t)data);
-    for (size_t i = 0; i < (size_t)width * height; i++) {
-        bgr[3 * i + 0] = rgba[4 * i + 2];
-        bgr[3 * i + 1] = rgba[4 * i + 1];
-        bgr[3 * i + 2] = rgba[4 * i + 0];
-    }
+    std::vector<uint8_t> bgr(bytes, 0);
+    for (size_t y = 0; y < (size_t)height; y++)
+        for (size_t x = 0; x < (size_t)width; x++) {
+            const uint8_t* px = rgba + 4 * (y * (size_t)width + x);
+            uint8_t* out = &bgr[y * row + 3 * x];
+            out[0] = px[2], out[1] = px[1], out[2] = px[0];
+        }
     FILE* f = std::fopen(path, "wb");
     if (!f) return rt_fail(RT_ERR_IO, std::string("cannot open for writing: ") + path);
     bool ok = std::fwrite(hdr, 1, 54, f) == 54 && std::fwrite(bgr.data(), 1, bgr.size(), f) == bgr.size();

@@ -783,8 +783,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     } guard{s};
     HIPCHK(hipGetDevice(&s->device));
 
-    // one slab: lights | geometry | Bezier segments | primitives | primitive extras | nodes | four-wide nodes | parents | leaves | texels, one copy
-    std::vector<DevPrimX> px((size_t)d->n_primitives);
+    // one slab: lights | geometry | Bezier segments | shading table | nodes | four-wide nodes | parents | leaves | candidate grid | texels, one copy
     std::vector<DevShade> shade((size_t)d->n_primitives);
     std::vector<DevGeom> geom((size_t)d->n_primitives), segs;
     std::vector<uint32_t> tex_off((size_t)d->n_textures);
@@ -798,21 +797,19 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (texel_bytes >= (1ull << 32)) return rt_fail(RT_ERR_LIMIT, "more than 4 GiB of textures");
     for (int i = 0; i < d->n_primitives; i++) {
         const rt_primitive& p = d->primitives[i];
-        DevPrimX& x = px[i];
-        x.tex_w = x.tex_h = 0, x.tex_off = 0, x.pad_ = 0;
+        int tw = 0, th = 0;
+        uint32_t toff = 0;
         if (p.material.texture >= 0) {
             const rt_texture& t = d->textures[p.material.texture];
-            x.tex_w = t.width, x.tex_h = t.height, x.tex_off = tex_off[p.material.texture];
+            tw = t.width, th = t.height, toff = tex_off[p.material.texture];
         }
         build_geom(d, p, geom[i], segs, T);
-        build_shade(p, x, shade[i]);
+        build_shade(p, tw, th, toff, shade[i]);
     }
     size_t off_l = 0;
     size_t off_g = align_up(off_l + sizeof(rt_light) * d->n_lights, 256);
     size_t off_s = align_up(off_g + sizeof(DevGeom) * d->n_primitives, 256);
-    size_t off_p = align_up(off_s + sizeof(DevGeom) * segs.size(), 256);
-    size_t off_x = align_up(off_p + sizeof(rt_primitive) * d->n_primitives, 256);
-    size_t off_sh = align_up(off_x + sizeof(DevPrimX) * d->n_primitives, 256);
+    size_t off_sh = align_up(off_s + sizeof(DevGeom) * segs.size(), 256);
     size_t off_n = align_up(off_sh + sizeof(DevShade) * d->n_primitives, 256);
     size_t off_n2 = align_up(off_n + sizeof(rt_bvh_node) * (size_t)d->n_nodes, 256);
     size_t off_np = align_up(off_n2 + sizeof(DevNode4) * T.nodes.size(), 256);
@@ -828,8 +825,6 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     if (d->n_lights) std::memcpy(&host[off_l], d->lights, sizeof(rt_light) * d->n_lights);
     if (d->n_primitives) std::memcpy(&host[off_g], geom.data(), sizeof(DevGeom) * d->n_primitives);
     if (!segs.empty()) std::memcpy(&host[off_s], segs.data(), sizeof(DevGeom) * segs.size());
-    if (d->n_primitives) std::memcpy(&host[off_p], d->primitives, sizeof(rt_primitive) * d->n_primitives);
-    if (d->n_primitives) std::memcpy(&host[off_x], px.data(), sizeof(DevPrimX) * d->n_primitives);
     if (d->n_primitives) std::memcpy(&host[off_sh], shade.data(), sizeof(DevShade) * d->n_primitives);
     if (d->n_nodes) std::memcpy(&host[off_n], d->nodes, sizeof(rt_bvh_node) * (size_t)d->n_nodes);
     if (!T.nodes.empty()) std::memcpy(&host[off_n2], T.nodes.data(), sizeof(DevNode4) * T.nodes.size());
@@ -864,8 +859,6 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     v.lights = (const rt_light*)(base + off_l);
     v.geom = (const DevGeom*)(base + off_g);
     v.segs = (const DevGeom*)(base + off_s);
-    v.prims = (const rt_primitive*)(base + off_p);
-    v.primx = (const DevPrimX*)(base + off_x);
     v.shade = (const DevShade*)(base + off_sh);
     v.nodes = (const rt_bvh_node*)(base + off_n);
     v.nodes4 = (const DevNode4*)(base + off_n2);

@@ -303,7 +303,7 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T, bool device_build) {
     }
 }
 
-static void build_shade(const rt_primitive& p, const DevPrimX& x, DevShade& o) {
+static void build_shade(const rt_primitive& p, int tex_w, int tex_h, uint32_t tex_off, DevShade& o) {
     using namespace hostmath;
     std::memset(&o, 0, sizeof(o));
     const rt_material& m = p.material;
@@ -311,7 +311,7 @@ static void build_shade(const rt_primitive& p, const DevPrimX& x, DevShade& o) {
     o.absor[0] = m.absor.x, o.absor[1] = m.absor.y, o.absor[2] = m.absor.z;
     o.diff = m.diff, o.spec = m.spec, o.refl = m.refl, o.refr = m.refr, o.rindex = m.rindex, o.drefl = m.drefl;
     o.type = p.type, o.texture = m.texture, o.is_light = p.is_light;
-    o.tex_w = x.tex_w, o.tex_h = x.tex_h, o.tex_off = x.tex_off;
+    o.tex_w = tex_w, o.tex_h = tex_h, o.tex_off = tex_off;
     auto put3 = [&](int i, h3 v) { o.tf[i] = v.x, o.tf[i + 1] = v.y, o.tf[i + 2] = v.z; };
     switch (p.type) {
         case RT_PRIM_SPHERE:

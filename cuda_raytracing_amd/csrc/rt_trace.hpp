@@ -73,13 +73,6 @@ enum { TF_SPH_O = 0, TF_SPH_DE = 3, TF_SPH_DC = 6, TF_SPH_X = 9, TF_PLN_DX = 0, 
        TF_SQR_O = 0, TF_SQR_DX = 3, TF_SQR_DY = 6, TF_SQR_DXX = 9, TF_SQR_DYY = 10, TF_CYL_O1 = 0, TF_CYL_O2 = 3, TF_CYL_AX = 6,
        TF_CYL_LEN = 9, TF_CYL_R = 10 };
 
-// Per-primitive shading extras (superseded by DevShade; kept for the record layout of the slab).
-struct DevPrimX {
-    int32_t tex_w, tex_h;
-    uint32_t tex_off;  // byte offset of the texture in the texel pool
-    uint32_t pad_;
-};
-
 struct DevScene {
     d3 bg_top, bg_bottom, camO, camN, camDx, camDy;
     int32_t cam_w, cam_h, shade_n, n_lights, n_prims;
@@ -92,8 +85,6 @@ struct DevScene {
     const rt_light* lights;        // read as RT_CONST
     const DevGeom* geom;           // read as RT_CONST, one per primitive
     const DevGeom* segs;           // read as RT_CONST, Bezier cylinder segments
-    const rt_primitive* prims;     // materials + texture frames, per-lane lookups
-    const DevPrimX* primx;
     const DevShade* shade;         // global copy of the shading table
     const rt_bvh_node* nodes;
     const DevNode4* nodes4;        // collapsed tree of the pruned walk

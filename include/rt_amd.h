@@ -222,7 +222,9 @@ int rt_host_scene_warning_count(const rt_host_scene* hs);
 const char* rt_host_scene_warning(const rt_host_scene* hs, int i);
 void rt_host_scene_free(rt_host_scene* hs);
 /* Write a 24-bit BMP the way BmpSave::SaveBMP does (CR/BmpSave.cpp:5-44): packed 54-byte
- * header, rows bottom-up, BGR, no row padding.  `rgba` is width*height*4 bytes, row 0 = bottom. */
+ * header, rows bottom-up, BGR.  Rows are padded to a multiple of 4 bytes as the format requires (the
+ * reference writes them unpadded; the files are byte-identical whenever width*3 is a multiple of 4,
+ * which covers every size the reference uses).  `rgba` is width*height*4 bytes, row 0 = bottom. */
 int rt_bmp_save_rgba(const char* path, const uint8_t* rgba, int width, int height);
 
 /* ---- device side ------------------------------------------------------------------------ */
