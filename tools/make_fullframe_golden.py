@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Full-size golden frame of the headline configuration from the CPU oracle (oracle/liboracle.so): c4_lucy, 1920x1080,
-32 samples per pixel, depth of field on, semantics preset gpu_ref, seed 1 - what `bench.py` renders.  Every ray is traced
-in reference order (several minutes on 8 cores), so the ray / node / triangle totals of the frame are the reference's.
-Writes tests/golden/render/c4_lucy_1080p32.npz: the 8-bit image (R, G, B planes, row 0 = bottom) and the counters.
-Usage: python tools/make_fullframe_golden.py [--threads N]"""
+"""Full-size golden frames of bench configurations from the CPU oracle (oracle/liboracle.so), with the settings `bench.py`
+renders them with (semantics preset gpu_ref, seed 1): headline = c4_lucy 1920x1080x32 spp, c2 = c2_textured_mirror
+1280x720x128, c3 = c3_orange 1920x1080x64.  Every ray is traced in reference order (minutes on 8 cores), so the ray / node /
+triangle totals of a frame are the reference's.  Writes tests/golden/render/<scene>_<height>p<spp>.npz: the 8-bit image
+(R, G, B planes, row 0 = bottom) and the counters.
+Usage: python tools/make_fullframe_golden.py [--config headline|c2|c3] [--threads N]"""
 import argparse
 import os
 import sys
@@ -23,11 +24,13 @@ from cuda_raytracing_amd.host import SCENE_DIR, HostScene  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "render", "c4_lucy_1080p32.npz"))
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3"])
     args = ap.parse_args()
-    W, H, spp = 1920, 1080, 32
-    hs = HostScene(os.path.join(SCENE_DIR, "c4_lucy.txt"))
-    st = orc.settings(spp=spp, dof=True, focal=1.35, aperture=1.0, seed=1, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
+    name, W, H, spp, aperture, focal = {"headline": ("c4_lucy", 1920, 1080, 32, 1.0, 1.35), "c2": ("c2_textured_mirror", 1280, 720, 128, 10.0, 10.2),
+                                        "c3": ("c3_orange", 1920, 1080, 64, 10.0, 14.5)}[args.config]
+    args.out = os.path.join(ROOT, "tests", "golden", "render", f"{name}_{H}p{spp}.npz")
+    hs = HostScene(os.path.join(SCENE_DIR, name + ".txt"))
+    st = orc.settings(spp=spp, dof=True, focal=focal, aperture=aperture, seed=1, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
     t0 = time.time()
     rgba, _, s = orc.render(hs, st, W, H, threads=args.threads)
     dt = time.time() - t0
@@ -35,7 +38,7 @@ def main():
                                                 "texture_fetches", "pixels")}
     # planes compress better than interleaved pixels
     np.savez_compressed(args.out, r=rgba[..., 0], g=rgba[..., 1], b=rgba[..., 2], width=W, height=H, spp=spp, seed=1,
-                        flags=int(abi.RT_MODE_GPU_REF), focal=1.35, aperture=1.0, oracle_seconds=dt,
+                        flags=int(abi.RT_MODE_GPU_REF), focal=focal, aperture=aperture, oracle_seconds=dt,
                         **{"ctr_" + k: np.uint64(v) for k, v in counters.items()})
     print(f"{args.out}: {os.path.getsize(args.out) / 1e6:.2f} MB, oracle {dt:.0f} s, {counters}")
 
