@@ -176,9 +176,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # RT_BENCH_REHEARSE=1: a dress rehearsal of the multi-rank path on a box with fewer GPUs than ranks - all ranks render on
+    # GPU 0 and the exchange runs over gloo on host copies of the frames.  The partition, the launcher, the packing order
+    # and the assembled frame are the real ones (rank 0 checks the frame against a single-rank render); the timings are not.
+    rehearse = world > 1 and os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    comm = "cpu" if rehearse else "cuda"
 
     scene_name, W, H, spp, dof, aperture, focal, preset = CONFIGS[args.config]
     scene_name, W, H, spp = args.scene or scene_name, args.width or W, args.height or H, args.spp or spp
@@ -189,11 +199,12 @@ def main():
     stream = torch.cuda.current_stream()
     ds.set_stream(stream.cuda_stream)
     image = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
-    gather = FrameGather(W, H, args.tile, rank, world, image.device)
+    gather = FrameGather(W, H, args.tile, rank, world, torch.device(comm))
+    frame = [None]
 
     def step():
         _, s = ds.render_frame(st, W, H, tile=args.tile, part=rank, n_parts=world, out=image)
-        gather.gather(image)
+        frame[0] = gather.gather(image.cpu() if rehearse else image)
         return s
 
     def sync():
@@ -220,8 +231,8 @@ def main():
         kernel_ms += last.kernel_ms
     sync()
     elapsed = time.perf_counter() - t0
-    rays = torch.tensor([float(last.rays), float(last.rays_primary), float(last.rays_traced)], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays = torch.tensor([float(last.rays), float(last.rays_primary), float(last.rays_traced)], dtype=torch.float64, device=comm)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=comm)
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -250,6 +261,11 @@ def main():
             "config": {"workload": f"{args.config}: {scene_name} ({describe(hs, abi)}); {W}x{H}, {spp} spp, {dof_txt}, semantics preset {preset}, pruned traversal",
                        "tile": args.tile, "partition": f"tile t -> rank t % {world}, gather to rank 0"},
         }
+        if rehearse:
+            whole, ws = ds.render_frame(st, W, H)  # the same frame on one rank
+            out["rehearsal"] = {"backend": "gloo, all ranks on GPU 0 (timings are not those of a multi-GPU run)",
+                                "frame_matches_single_rank": bool((frame[0].numpy() == whole).all()),
+                                "rays_match_single_rank": bool(ws.rays == int(frame_rays))}
         picked, _, _ = ds.shared_walk
         n_prims = hs.desc.n_primitives
         cap = 16 if n_prims <= 16 else 64 if n_prims <= 64 else 0

@@ -86,3 +86,21 @@ def test_renderer_cli_with_a_gpu_count(tmp_path):
         assert p.returncode == 0, p.stderr
         outs.append(out.read_bytes())
     assert outs[0] == outs[1]
+
+
+def test_bench_two_and_three_ranks_rehearsal():
+    """`bench.py --gpus N` end to end on the one-GPU box: it starts its own ranks, every rank renders its tiles (on GPU 0),
+    the packs are gathered (over gloo, host copies) and rank 0's assembled frame must equal a single-rank render."""
+    import json
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ, RT_BENCH_REHEARSE="1")
+    env.pop("WORLD_SIZE", None)
+    for n, cfg in ((2, ["--config", "c1"]), (3, ["--config", "headline", "--width", "200", "--height", "136", "--spp", "2"])):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                            "--no-strict"] + cfg, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["value"] > 0
+        assert line["rehearsal"]["frame_matches_single_rank"] and line["rehearsal"]["rays_match_single_rank"], line["rehearsal"]
