@@ -30,3 +30,19 @@ for n in (1, 2, 4, 8):
         ks.append(s.kernel_ms)
     print(f"world {n}: kernel ms per rank min {min(ks):.2f} max {max(ks):.2f} sum {sum(ks):.2f}; wall per call max {max(ws):.2f}; "
           f"predicted efficiency {ks and (sum(ks) / n) / max(ws) * 100:.0f}% of ideal split", flush=True)
+
+# fixed cost of the exchange on rank 0 besides the transfer itself: one pack kernel per rank, n - 1 unpack kernels on rank 0
+lib = abi.load_library()
+for n in (2, 4, 8):
+    pk = torch.zeros(int(lib.rt_member_pixels(W, H, 32, 0, n)) + 64, dtype=torch.int32, device="cuda")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    for _ in range(2):  # second round is timed
+        ev[0].record()
+        abi.check(lib.rt_pack_tiles(image.data_ptr(), W, H, 32, 1, n, pk.data_ptr()))
+        ev[1].record()
+        for r in range(1, n):
+            abi.check(lib.rt_unpack_tiles(pk.data_ptr(), W, H, 32, r, n, image.data_ptr()))
+        ev[2].record()
+        torch.cuda.synchronize()
+    print(f"world {n}: pack kernel {ev[0].elapsed_time(ev[1]) * 1e3:.0f} us, {n - 1} unpack kernels {ev[1].elapsed_time(ev[2]) * 1e3:.0f} us "
+          f"({pk.numel() * 4 / 1e6:.2f} MB per rank)", flush=True)
