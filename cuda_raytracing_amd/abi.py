@@ -167,6 +167,7 @@ _SIGNATURES = {
     "rt_scene_tree_build_ms": (C.c_double, [C.c_void_p]),
     "rt_scene_shared_walk": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rt_scene_waves_per_simd": (C.c_int, [C.c_void_p]),
+    "rt_scene_deferred_shadows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rt_scene_create": (C.c_int, [_P(SceneDesc), _P(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render_tile": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p, _P(Stats)]),

@@ -573,6 +573,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(RenderParams P) {
     *reinterpret_cast<uint32_t*>(P.out + ((size_t)py * (size_t)P.tex_w + (size_t)px) * 4) = rgba;
 }
 
+#include "rt_defer.hpp"
+
 // ---- debug kernel: primary ray of every pixel, reference-order walk with a visit log ------------
 struct ProbeParams {
     DevScene sc;
@@ -624,6 +626,12 @@ struct Workspace {
     double* path_out = nullptr;              // colours of the finished paths of one launch
     size_t path_out_bytes = 0;
     bool fixed = false;                      // true: the buffers above are all there is (nothing may be allocated or grown)
+    // the three-kernel render (rt_defer.hpp): node records, shadow jobs per lamp, allocation counters, last node per path
+    NodeRec* nodes = nullptr;
+    JobRec* jobs = nullptr;
+    uint32_t* alloc = nullptr;
+    uint32_t* last_node = nullptr;
+    size_t nodes_cap = 0, jobs_cap = 0, last_cap = 0;
 };
 
 struct rt_scene {
@@ -636,6 +644,9 @@ struct rt_scene {
     size_t image_bytes = 0;
     int shared_walk = 0;                   // shadow mesh walks shared by the wave (render_kernel<.., SHARE = true>): 0 = no, 1 = yes
     int waves = RT_WAVES_PER_SIMD;         // kernel build the scene gets: RT_WAVES_PER_SIMD, or 4 for mesh-heavy scenes (shared variant only)
+    int defer = 0;                         // pruned renders go through the three-kernel path (rt_defer.hpp) instead of the one kernel
+    uint32_t launch_id = 0;                // tag of the last launch of the three-kernel render
+    int defer_fallbacks = 0;               // calls that had to be rendered again by the one kernel because a record buffer was too small
     size_t n_blocks = 0;                   // blocks in ws.blocks: those of last_tiles
     std::vector<Tile> last_tiles;
     int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
@@ -759,6 +770,10 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (s->ws.queue) (void)hipFree(s->ws.queue);
     if (s->ws.counters) (void)hipFree(s->ws.counters);
     if (s->image) (void)hipFree(s->image);
+    if (s->ws.nodes) (void)hipFree(s->ws.nodes);
+    if (s->ws.jobs) (void)hipFree(s->ws.jobs);
+    if (s->ws.alloc) (void)hipFree(s->ws.alloc);
+    if (s->ws.last_node) (void)hipFree(s->ws.last_node);
     if (s->ws.path_out) (void)hipFree(s->ws.path_out);
     if (s->ws.blocks) (void)hipFree(s->ws.blocks);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -879,6 +894,13 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->shared_walk = (v.mesh_scale_max > 0.0 && v.n_prims <= RT_SHADE_LDS) ? 1 : 0;
     if (const char* e = std::getenv("RT_AMD_SHARED_WALK"))
         if ((e[0] == '0' || e[0] == '1') && v.n_prims <= RT_SHADE_LDS) s->shared_walk = e[0] - '0';
+    // The three-kernel render needs room for every lamp in a node record and the primitive index in 24 bits.
+    {
+        const bool can = d->n_lights <= RT_DEFER_LAMPS && d->n_primitives < (1 << 24) && v.shade_n < (1 << 16);
+        s->defer = 0;
+        if (const char* e = std::getenv("RT_AMD_DEFER"))
+            if (e[0] == '1' && can) s->defer = 1;
+    }
     // Four waves per SIMD where shadow walks over meshes carry the frame: several meshes, or one large one (more triangles than
     // 64 Ki).  RT_AMD_WAVES=3|4 overrides the rule.
     {
@@ -943,8 +965,11 @@ static int blocks_of(const std::vector<Tile>& tiles, std::vector<BlockRec>& recs
 }
 
 // Render the given tiles into `dst` (device image).  Fills kernel time and counters.
+#ifndef RT_DEFER_PATHS
+#define RT_DEFER_PATHS (1ull << 25)  // most paths of one launch of the three-kernel render (node records + jobs: about 0.9 KB per path)
+#endif
 static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h,
-                        const std::vector<Tile>& tiles, uint8_t* dst, rt_stats* stats) {
+                        const std::vector<Tile>& tiles, uint8_t* dst, rt_stats* stats, bool allow_defer = true) {
     uint64_t pixels = 0;
     for (const Tile& t : tiles) pixels += (uint64_t)t.w * t.h;
     // The block list of the scene's own workspace is kept from call to call: a renderer asks for the same tiles frame after frame.
@@ -979,6 +1004,8 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v >= 64 && v < launch_paths) launch_paths = v;
     }
+    const bool defer = allow_defer && !strict && !ws.fixed && s->defer == 1;
+    if (defer) launch_paths = std::min<uint64_t>(launch_paths, RT_DEFER_PATHS);
     if (ws.fixed) {
         const uint64_t cap = ws.path_out_bytes / (3 * sizeof(double));
         if (cap < block_paths) return rt_fail(RT_ERR_LIMIT, "too many samples per pixel for the fixed workspace (one 8x8 block must fit)");
@@ -994,6 +1021,45 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         ws.path_out_bytes = out_bytes;
     }
     HIPCHK(hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));
+    DeferParams D{};
+    if (defer) {
+        // record buffers for the largest launch of this call: six nodes per path (a path has one node per ray it traces), and per
+        // lamp 1.25 jobs per path; a call that needs more is rendered again by the one kernel (the overflow word tells)
+        const uint64_t paths = std::min(blocks, chunk_blocks) * block_paths;
+        // (every wave of the path kernel may leave most of one allocation chunk unused when it ends)
+        const uint64_t path_waves = 4 * std::min<uint64_t>((uint64_t)s->cus * RT_PATH_WAVES, (paths + 255) / 256);
+        size_t want_nodes = (size_t)(6 * paths + path_waves * RT_NODE_CHUNK + 65536);
+        if (const char* e = std::getenv("RT_AMD_DEFER_NODES")) {  // a fixed node capacity (tests of the fall-back to the one kernel)
+            const unsigned long long v = std::strtoull(e, nullptr, 10);
+            if (v >= 1) want_nodes = (size_t)v, ws.nodes_cap = std::min(ws.nodes_cap, want_nodes);
+        }
+        size_t want_jobs = (size_t)(3 * paths + path_waves * RT_JOB_CHUNK + 65536);  // per lamp: at most one job per shaded node
+        want_jobs = std::min<size_t>(want_jobs, (size_t)(0x7FFFFFFFull / (uint64_t)std::max(1, s->dev.shade_n)));
+        if (ws.nodes_cap < want_nodes) {
+            if (ws.nodes) (void)hipFree(ws.nodes);
+            ws.nodes = nullptr, ws.nodes_cap = 0;
+            HIPCHK(hipMalloc(&ws.nodes, want_nodes * sizeof(NodeRec)));
+            ws.nodes_cap = want_nodes;
+        }
+        if (ws.jobs_cap < want_jobs) {
+            if (ws.jobs) (void)hipFree(ws.jobs);
+            ws.jobs = nullptr, ws.jobs_cap = 0;
+            const size_t bytes = want_jobs * (size_t)std::max(1, s->dev.n_lights) * sizeof(JobRec);
+            HIPCHK(hipMalloc(&ws.jobs, bytes));
+            HIPCHK(hipMemsetAsync(ws.jobs, 0, bytes, g_stream));  // no slot carries a launch tag yet
+            ws.jobs_cap = want_jobs;
+        }
+        if (ws.last_cap < paths) {
+            if (ws.last_node) (void)hipFree(ws.last_node);
+            ws.last_node = nullptr, ws.last_cap = 0;
+            HIPCHK(hipMalloc(&ws.last_node, (size_t)paths * sizeof(uint32_t)));
+            ws.last_cap = (size_t)paths;
+        }
+        if (!ws.alloc) HIPCHK(hipMalloc(&ws.alloc, 256));
+        D.nodes = ws.nodes, D.jobs = ws.jobs, D.alloc = ws.alloc, D.last_node = ws.last_node;
+        D.nodes_cap = (uint32_t)std::min<size_t>(std::min(ws.nodes_cap, want_nodes), 0xFFFFFFF0u), D.jobs_cap = (uint32_t)ws.jobs_cap;
+        D.overflow = ws.counters + (CTR_ALL + 15);
+    }
 
     RenderParams P;
     P.sc = s->dev;
@@ -1015,6 +1081,29 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         uint64_t grid = (uint64_t)s->cus * bpc;
         const uint64_t want_blocks = ((uint64_t)P.n_paths + 255) / 256;
         if (grid > want_blocks) grid = want_blocks;
+        if (defer) {
+            // path kernel (no shadow rays) -> shadow kernel (every job) -> fold kernel (colours), see rt_defer.hpp
+            HIPCHK(hipMemsetAsync(ws.alloc, 0, 256, g_stream));
+            if (++s->launch_id == 0) s->launch_id = 1;
+            D.launch_id = s->launch_id;
+            HIPCHK(hipMemsetAsync(ws.last_node, 0xFF, (size_t)P.n_paths * sizeof(uint32_t), g_stream));
+            uint64_t pg = std::min<uint64_t>((uint64_t)s->cus * RT_PATH_WAVES, want_blocks);
+            const dim3 gp((unsigned)pg), t(256);
+            if (P.sc.n_prims <= 16) hipLaunchKernelGGL((path_kernel<16>), gp, t, 0, g_stream, P, D);
+            else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((path_kernel<RT_SHADE_LDS>), gp, t, 0, g_stream, P, D);
+            else hipLaunchKernelGGL((path_kernel<0>), gp, t, 0, g_stream, P, D);
+            HIPCHK(hipGetLastError());
+            const dim3 gs((unsigned)((uint64_t)s->cus * RT_SHADOW_WAVES));
+            if (s->dev.mesh_scale_max > 0.0) hipLaunchKernelGGL((shadow_kernel<true>), gs, t, 0, g_stream, P, D);
+            else hipLaunchKernelGGL((shadow_kernel<false>), gs, t, 0, g_stream, P, D);
+            HIPCHK(hipGetLastError());
+            const dim3 gf((unsigned)std::min<uint64_t>(want_blocks, (uint64_t)s->cus * 8));
+            hipLaunchKernelGGL(fold_kernel, gf, t, 0, g_stream, P, D);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, g_stream, P);
+            HIPCHK(hipGetLastError());
+            return RT_OK;
+        }
         const dim3 g((unsigned)grid), t(256);
         if (strict) hipLaunchKernelGGL((render_kernel<true, 0, false>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= 16 && four) hipLaunchKernelGGL((render_kernel<false, 16, true, 4>), g, t, 0, g_stream, P);
@@ -1037,6 +1126,10 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
     unsigned long long c[CTR_ALL + 16];
     HIPCHK(hipMemcpyAsync(c, ws.counters, sizeof(c), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+    if (defer && c[CTR_ALL + 15] != 0ull) {  // a record buffer was too small for this call: the one kernel renders it
+        s->defer_fallbacks++;
+        return launch_tiles(s, ws, st, tex_w, tex_h, cam_w, cam_h, tiles, dst, stats, false);
+    }
 #ifdef RT_UTIL_COUNTERS
     std::fprintf(stderr, "[util] shadow lanes used %.1f%% (%llu of %llu slots), closest-hit lanes used %.1f%% (%llu of %llu slots)\n",
                  100.0 * c[CTR_U_SHADOW_ITEMS] / (double)(c[CTR_U_SHADOW_SLOTS] ? c[CTR_U_SHADOW_SLOTS] : 1), c[CTR_U_SHADOW_ITEMS], c[CTR_U_SHADOW_SLOTS],

@@ -38,6 +38,13 @@ class DeviceScene:
         return choice, a.value, b.value
 
     @property
+    def deferred_shadows(self):
+        """(in use, calls that fell back to the one-kernel render) of the three-kernel render."""
+        n = C.c_int(0)
+        on = int(self._lib.rt_scene_deferred_shadows(self._h, C.byref(n)))
+        return on, n.value
+
+    @property
     def waves_per_simd(self):
         return int(self._lib.rt_scene_waves_per_simd(self._h))
 

@@ -257,6 +257,13 @@ int rt_scene_shared_walk(const rt_scene* scene, double* plain_ms, double* shared
  * only where shadow rays walking meshes carry the frame; scenes with several meshes or more than 65536 triangles get it
  * (RT_AMD_WAVES=3|4 overrides).  Returns the build this scene's pruned renders use.  No counterpart in the reference. */
 int rt_scene_waves_per_simd(const rt_scene* scene);
+/* Pruned renders have a second form: three lean kernels instead of one large one.  The paths are traced without their shadow
+ * rays (a record per ray says what was hit and which shadow rays are still open), a second kernel traces all shadow rays, a
+ * third computes the colours from the records; same image bit for bit.  It needs about 0.9 KB of device memory per path of a
+ * launch (launches are cut at 2^25 paths) and at most 4 lamps.  Returns whether this scene's pruned renders use it
+ * (RT_AMD_DEFER=0|1 in the environment at rt_scene_create decides) and, in *fallbacks, how many calls had to be rendered
+ * again by the one kernel because a record buffer was too small.  No counterpart in the reference. */
+int rt_scene_deferred_shadows(const rt_scene* scene, int* fallbacks);
 
 /* Upload a scene: one slab, one copy.  Replaces createCudaSceneFromCPUScene
  * (CR/Renderer_CUDA.cpp:298-335). */

@@ -257,6 +257,36 @@ def test_many_overlapping_meshes_shared_plain_and_strict_agree(tmp_path, monkeyp
     assert fstats.rays == sstats.rays
 
 
+@pytest.mark.parametrize("name,W,H,spp,flags", [
+    ("c4_lucy", 320, 180, 4, abi.RT_MODE_GPU_REF), ("c5_final", 256, 144, 3, abi.RT_MODE_GPU_REF), ("c3_orange", 240, 136, 4, abi.RT_MODE_GPU_REF),
+    ("t_icosa", 96, 72, 5, abi.RT_MODE_CPU_REF), ("t_bezier", 96, 72, 2, abi.RT_MODE_GPU_REF & ~abi.RT_F_BEZIER_STACKED),
+])
+def test_three_kernel_render_equals_one_kernel_render(monkeypatch, name, W, H, spp, flags):
+    """RT_AMD_DEFER=1: paths without shadow rays -> all shadow rays -> colours from the records.  Same image, same ray counts;
+    with room for too few records the call falls back to the one kernel and still gives the same image."""
+    hs = scene(name)
+    st = orc.settings(spp=spp, dof=True, focal=9.0, aperture=1.0, seed=13, flags=flags)
+    monkeypatch.delenv("RT_AMD_DEFER", raising=False)
+    with device_scene(hs) as ds:
+        assert ds.deferred_shadows == (0, 0)
+        one, os_ = ds.render_frame(st, W, H)
+    monkeypatch.setenv("RT_AMD_DEFER", "1")
+    with device_scene(hs) as ds:
+        three, ts = ds.render_frame(st, W, H)
+        rect = (W // 4 + 3, H // 4 + 1, W // 2, H // 2)
+        part = np.zeros_like(three)
+        ds.render_tile(st, W, H, rect, out=part)
+        assert ds.deferred_shadows == (1, 0)
+        monkeypatch.setenv("RT_AMD_DEFER_NODES", "1000")  # far too few node records: the one kernel takes over
+        again, as_ = ds.render_frame(st, W, H)
+        assert ds.deferred_shadows == (1, 1)
+    assert np.array_equal(three, one) and np.array_equal(again, one)
+    x0, y0, w, h = rect
+    assert np.array_equal(part[y0:y0 + h, x0:x0 + w], one[y0:y0 + h, x0:x0 + w])
+    for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_shadow_traced", "shaded_hits", "texture_fetches", "pixels"):
+        assert getattr(ts, k) == getattr(os_, k) == getattr(as_, k), k
+
+
 FLAGS = [abi.RT_F_NORMALIZE_PRIMARY, abi.RT_F_SKY_Y, abi.RT_F_TIE_LATER_WINS, abi.RT_F_SHADOW_SELF_SKIP, abi.RT_F_SQUARE_UV_NO_ORIGIN,
          abi.RT_F_TEX_U8_TAPS, abi.RT_F_PIXEL_MAP_TRUNC, abi.RT_F_MESH_RAW_DIR]
 

@@ -5,11 +5,14 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = "/tmp/kres.so"
 extra = []
+show_all = False
 a = sys.argv[1:]
 while a:
     x = a.pop(0)
     if x == "-o":
         out = a.pop(0)
+    elif x == "--all":
+        show_all = True
     else:
         extra.append(x)
 cs = os.path.join(ROOT, "cuda_raytracing_amd", "csrc")
@@ -36,9 +39,9 @@ for line in p.stderr.splitlines():
         k, v = t.split(":", 1)
         rows[cur][k.strip()] = v.strip()
 for name, r in rows.items():
-    if "render_kernel" not in name and "--all" not in extra:
+    if not show_all and not any(k in name for k in ("render_kernel", "path_kernel", "shadow_kernel", "fold_kernel")):
         continue
     m = re.match(r"_Z13render_kernelILb(\d)ELi(\d+)ELb(\d)E", name)
-    d = "render_kernel<strict=%s, cap=%s, share=%s>" % m.groups() if m else name
+    d = "render_kernel<strict=%s, cap=%s, share=%s>" % m.groups() if m else name[:60]
     print(f"{d[:60]:60s} VGPR {r.get('VGPRs')} AGPR {r.get('AGPRs')} spill {r.get('VGPRs Spill', r.get('VGPR Spill'))} scratch {r.get('ScratchSize [bytes/lane]')} "
           f"occ {r.get('Occupancy [waves/SIMD]')} LDS {r.get('LDS Size [bytes/block]')} SGPR {r.get('TotalSGPRs')}")
