@@ -59,3 +59,22 @@ def test_ownership_partitions_the_image():
         assert (total == 1).all()
         counts = [owned_mask(w, h, tile, r, world).sum() for r in range(world)]
         assert max(counts) - min(counts) <= 3 * tile * tile  # interleaving keeps the shares close
+
+
+def test_packed_order_covers_exactly_the_owned_pixels():
+    """A rank's packed buffer lists each of its pixels once, tile after tile; the library's count agrees (no GPU needed)."""
+    from cuda_raytracing_amd import abi
+    from cuda_raytracing_amd.distributed import packed_index
+    lib = abi.load_library()
+    for (w, h, tile, world) in [(100, 70, 16, 3), (64, 48, 32, 2), (33, 17, 8, 4), (1920, 1080, 32, 8)]:
+        seen = np.zeros(w * h, dtype=np.int32)
+        for r in range(world):
+            idx = packed_index(w, h, tile, r, world)
+            assert idx.size == int(lib.rt_member_pixels(w, h, tile, r, world))
+            assert np.array_equal(np.sort(idx), np.flatnonzero(owned_mask(w, h, tile, r, world).reshape(-1)))
+            seen[idx] += 1
+            # inside a tile the order is row-major: the first tile's first row is contiguous in the image
+            first_row = idx[: min(tile, w)]
+            assert np.array_equal(first_row, first_row[0] + np.arange(first_row.size))
+        assert (seen == 1).all()
+    assert lib.rt_member_pixels(64, 48, 32, 2, 2) == -1
