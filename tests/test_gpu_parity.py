@@ -464,6 +464,27 @@ def test_other_configs_at_full_size(name, W, H, spp, aperture, focal, blocks):
             assert getattr(stats, k) == int(g["ctr_" + k]), (k, getattr(stats, k), int(g["ctr_" + k]))
 
 
+def test_final_scene_full_frame_against_oracle_fixture():
+    """C5's scene (Lucy + bunny, 102,897 triangles, three sphere lamps) at its full 1920x1080 with 4 of its 128 samples per pixel:
+    every pixel against the frame the CPU oracle rendered (committed fixture), reference-order counters against its totals."""
+    g = np.load(os.path.join(GOLD, "render", "c5_final_1080p4.npz"))
+    W, H, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+    assert (W, H, spp) == (1920, 1080, 4)
+    hs = scene("c5_final")
+    st = orc.settings(spp=spp, dof=True, focal=float(g["focal"]), aperture=float(g["aperture"]), seed=int(g["seed"]), flags=int(g["flags"]))
+    with device_scene(hs) as ds:
+        assert ds.waves_per_simd == 4 and ds.shared_walk[0] == 1  # the mesh-heavy build
+        fast, fstats = ds.render_frame(st, W, H)
+        st.flags |= abi.RT_F_STRICT_TRAVERSAL
+        strict, sstats = ds.render_frame(st, W, H)
+    assert np.array_equal(fast, strict), "pruned traversal changed the frame"
+    ref = np.stack([g["r"], g["g"], g["b"], np.full((H, W), 255, np.uint8)], -1)
+    assert_colour_close(fast, ref, "c5_final frame against the oracle's frame")
+    for k in ("rays_primary", "rays_secondary", "rays_shadow", "nodes_visited", "tris_tested", "shaded_hits", "texture_fetches", "pixels"):
+        assert getattr(sstats, k) == int(g["ctr_" + k]), (k, getattr(sstats, k), int(g["ctr_" + k]))
+    assert fstats.rays == sstats.rays
+
+
 def test_more_than_64_primitives(tmp_path):
     """Above 64 primitives the per-lamp candidate masks are off and the shading table stays in global memory."""
     rng = np.random.default_rng(7)

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Full-size golden frames of bench configurations from the CPU oracle (oracle/liboracle.so), with the settings `bench.py`
 renders them with (semantics preset gpu_ref, seed 1): headline = c4_lucy 1920x1080x32 spp, c2 = c2_textured_mirror
-1280x720x128, c3 = c3_orange 1920x1080x64.  Every ray is traced in reference order (minutes on 8 cores), so the ray / node /
+1280x720x128, c3 = c3_orange 1920x1080x64, c5x4 = c5_final 1920x1080 at 4 samples per pixel (its 128 would take the oracle hours).  Every ray is traced in reference order (minutes on 8 cores), so the ray / node /
 triangle totals of a frame are the reference's.  Writes tests/golden/render/<scene>_<height>p<spp>.npz: the 8-bit image
 (R, G, B planes, row 0 = bottom) and the counters.
-Usage: python tools/make_fullframe_golden.py [--config headline|c2|c3] [--threads N]"""
+Usage: python tools/make_fullframe_golden.py [--config headline|c2|c3|c5x4] [--threads N]"""
 import argparse
 import os
 import sys
@@ -24,10 +24,11 @@ from cuda_raytracing_amd.host import SCENE_DIR, HostScene  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3"])
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c5x4"])
     args = ap.parse_args()
     name, W, H, spp, aperture, focal = {"headline": ("c4_lucy", 1920, 1080, 32, 1.0, 1.35), "c2": ("c2_textured_mirror", 1280, 720, 128, 10.0, 10.2),
-                                        "c3": ("c3_orange", 1920, 1080, 64, 10.0, 14.5)}[args.config]
+                                        "c3": ("c3_orange", 1920, 1080, 64, 10.0, 14.5),
+                                        "c5x4": ("c5_final", 1920, 1080, 4, 150.0, 168.0)}[args.config]  # C5's frame at 4 of its 128 samples
     args.out = os.path.join(ROOT, "tests", "golden", "render", f"{name}_{H}p{spp}.npz")
     hs = HostScene(os.path.join(SCENE_DIR, name + ".txt"))
     st = orc.settings(spp=spp, dof=True, focal=focal, aperture=aperture, seed=1, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
