@@ -79,7 +79,7 @@ def describe(hs, abi):
 
 def flops_model(s):
     """Double-precision operations the launch performs, from its own counters: per four-wide node visited 4 slab tests
-    of 30 flop (SURVEY's per-test figure; they run in single precision here), 60 per triangle test, 40 per analytic
+    of 30 flop (six planes, compare and select; they run in single precision here), 60 per triangle test, 40 per analytic
     primitive test (every ray meets every top-level primitive of the scene), 50 per shaded hit and light, 25 per texture
     fetch.  A model, not a measurement: it prices useful arithmetic, the instruction count prices everything."""
     rays = s["rays_traced"]

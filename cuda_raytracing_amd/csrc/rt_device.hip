@@ -400,7 +400,11 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
                 const DevShade& m = shade[h.prim];
                 d3 acc = D3(0, 0, 0);
                 if (need_shade) acc = acc + local;
+#ifdef RT_ABLATE_SECONDARY  // timing experiments only: primary rays and their shading, nothing after them
+                const bool has_refl = false, has_refr = false;
+#else
                 const bool has_refl = m.refl > RT_EPS, has_refr = m.refr > RT_EPS;
+#endif
                 if (has_refl || has_refr) {
                     const int k = sp;
                     f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;

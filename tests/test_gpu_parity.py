@@ -485,6 +485,34 @@ def test_final_scene_full_frame_against_oracle_fixture():
     assert fstats.rays == sstats.rays
 
 
+def test_4k_frame_bands_against_oracle_fixture():
+    """C4 (c4_lucy at 3840x2160x32 with its lens): 34 bands of 8 rows spread over the whole height (1.04 M of the 8.3 M pixels)
+    against what the CPU oracle rendered for them (committed fixture); reference-order counters of the bands against its totals."""
+    g = np.load(os.path.join(GOLD, "render", "c4_lucy_2160p32_bands.npz"))
+    W, H, spp, rows = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["band_rows"])
+    assert (W, H, spp) == (3840, 2160, 32)
+    hs = scene("c4_lucy")
+    st = orc.settings(spp=spp, dof=True, focal=float(g["focal"]), aperture=float(g["aperture"]), seed=int(g["seed"]), flags=int(g["flags"]))
+    keys = ("rays_primary", "rays_secondary", "rays_shadow", "nodes_visited", "tris_tested", "shaded_hits", "texture_fetches", "pixels")
+    total = dict.fromkeys(keys, 0)
+    with device_scene(hs) as ds:
+        fast, fstats = ds.render_frame(st, W, H)
+        st.flags |= abi.RT_F_STRICT_TRAVERSAL
+        strict = np.zeros((H, W, 4), np.uint8)
+        for y0 in g["band_y0"]:
+            _, s = ds.render_tile(st, W, H, (0, int(y0), W, rows), out=strict)
+            for k in keys:
+                total[k] += getattr(s, k)
+    pick = np.concatenate([np.arange(int(y0), int(y0) + rows) for y0 in g["band_y0"]])
+    assert np.array_equal(fast[pick], strict[pick]), "pruned traversal changed the bands"
+    ref = np.stack([g["r"], g["g"], g["b"], np.full(g["r"].shape, 255, np.uint8)], -1)
+    assert ref.shape[0] == len(pick) == 34 * 8
+    assert_colour_close(fast[pick], ref, "c4_lucy 4K bands against the oracle's")
+    for k in keys:
+        assert total[k] == int(g["ctr_" + k]), (k, total[k], int(g["ctr_" + k]))
+    assert fstats.pixels == W * H
+
+
 def test_more_than_64_primitives(tmp_path):
     """Above 64 primitives the per-lamp candidate masks are off and the shading table stays in global memory."""
     rng = np.random.default_rng(7)
