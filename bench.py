@@ -269,7 +269,7 @@ def main():
         picked, _, _ = ds.shared_walk
         n_prims = hs.desc.n_primitives
         cap = 16 if n_prims <= 16 else 64 if n_prims <= 64 else 0
-        kname = "render_kernel<false, %d, %s>" % (cap, "true" if picked == 1 else "false")
+        kname = "render_kernel<false, %d, %s%s>" % (cap, "true" if picked == 1 else "false", ", 4" if ds.waves_per_simd == 4 else "")
         out["config"]["shadow_walk_variant"] = {0: "plain", 1: "shared"}[picked]
         kavg = kernel_ms / args.steps
         pmc, pmc_path = profile_counters(args.config)

@@ -104,3 +104,30 @@ def test_bench_two_and_three_ranks_rehearsal():
         line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == n and line["value"] > 0
         assert line["rehearsal"]["frame_matches_single_rank"] and line["rehearsal"]["rays_match_single_rank"], line["rehearsal"]
+
+
+def test_exchange_calls_over_rccl_with_one_rank(tmp_path):
+    """The collectives `bench.py --gpus N` issues, on the real backend ("nccl" = RCCL) with the tensors it passes them: the
+    gather of packed int32 tiles on the device, the float64 sum / max reductions, the barrier.  One rank is all a one-GPU box
+    can hold (RCCL refuses two ranks on one GPU); it shows that the backend comes up and accepts these calls here."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    script = tmp_path / "one_rank.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from cuda_raytracing_amd.distributed import FrameGather\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "g = FrameGather(100, 70, 16, 0, 2, torch.device('cuda'))  # the buffers of rank 0 of a two-rank job\n"
+        "g.pack.copy_(torch.arange(g.max_count, dtype=torch.int32, device='cuda'))\n"
+        "dist.gather(g.pack, g.recv[:1], dst=0)\n"
+        "t = torch.tensor([3.0, 5.0], dtype=torch.float64, device='cuda')\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.SUM); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier(); torch.cuda.synchronize()\n"
+        "assert torch.equal(g.recv[0], g.pack) and t.tolist() == [3.0, 5.0]\n"
+        "dist.destroy_process_group(); print('rccl ok')\n")
+    from cuda_raytracing_amd.launch import free_port
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, p.stderr[-3000:]
