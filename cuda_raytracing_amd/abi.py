@@ -165,6 +165,7 @@ _SIGNATURES = {
     "rt_set_stream": (C.c_int, [C.c_void_p]),
     "rt_set_tree_builder": (C.c_int, [C.c_int]),
     "rt_scene_tree_build_ms": (C.c_double, [C.c_void_p]),
+    "rt_scene_check_trees": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "rt_scene_shared_walk": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rt_scene_waves_per_simd": (C.c_int, [C.c_void_p]),
     "rt_scene_deferred_shadows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

@@ -20,13 +20,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_amd.h"
@@ -657,6 +660,9 @@ struct rt_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int desc_cam_w = 0, desc_cam_h = 0;
     float tree_build_ms = 0.0f;  // device time of the four-wide tree build, 0 if the host built the trees
+    std::vector<int32_t> tree_roots;               // per mesh: root of its four-wide tree, -1 = none (rt_scene_check_trees)
+    std::vector<std::vector<uint32_t>> tree_tris;  // per mesh with such a tree: leaf indices of its triangles
+    size_t n_nodes4 = 0, n_leaves = 0;
 };
 
 // ---- fixed workspace of rt_render_tile_noalloc ----------------------------------------------------
@@ -807,7 +813,8 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<DevGeom> geom((size_t)d->n_primitives), segs;
     std::vector<uint32_t> tex_off((size_t)d->n_textures);
     Tree4 T;
-    build_tree4(d, T, tree_builder_choice() == 1);
+    const int tree_builder = tree_builder_choice();
+    build_tree4(d, T, tree_builder != 0);
     size_t texel_bytes = 0;
     for (int i = 0; i < d->n_textures; i++) {
         tex_off[i] = (uint32_t)texel_bytes;
@@ -856,8 +863,9 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     HIPCHK(hipMalloc(&s->slab, s->slab_bytes));
     HIPCHK(hipMemcpy(s->slab, host.data(), s->slab_bytes, hipMemcpyHostToDevice));
     uint8_t* base = (uint8_t*)s->slab;
-    rc = run_tree_jobs(T, (DevNode4*)(base + off_n2), (const rt_bvh_leaf*)(base + off_f), &s->tree_build_ms);
+    rc = run_tree_jobs(T, (DevNode4*)(base + off_n2), (const rt_bvh_leaf*)(base + off_f), &s->tree_build_ms, tree_builder == 2);
     if (rc) return rc;
+    s->tree_roots = T.mesh_root4, s->tree_tris = std::move(T.mesh_tris), s->n_nodes4 = T.nodes.size(), s->n_leaves = (size_t)d->n_leaves;
     DevScene& v = s->dev;
     v.bg_top = d3{d->background_top.x, d->background_top.y, d->background_top.z};
     v.bg_bottom = d3{d->background_bottom.x, d->background_bottom.y, d->background_bottom.z};

@@ -62,6 +62,7 @@ struct Tree4 {
     std::vector<DevNode4> nodes;
     std::vector<uint32_t> node_parent, leaf_parent;   // per binary node / per leaf
     std::vector<int32_t> mesh_root4;                  // per mesh: root DevNode4 index, -1 = use the stackless walk
+    std::vector<std::vector<uint32_t>> mesh_tris;     // per mesh with a four-wide tree: the leaf indices of its triangles
     std::vector<TreeJob> jobs;
 };
 // set by rt_set_tree_builder for the calling thread (like the render stream), read by that thread's next rt_scene_create
@@ -172,6 +173,7 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T, bool device_build) {
     T.node_parent.assign(d->n_nodes, RT_REF_END);
     T.leaf_parent.assign(d->n_leaves, RT_REF_END);
     T.mesh_root4.assign(d->n_meshes, -1);
+    T.mesh_tris.assign(d->n_meshes, {});
     bool shared = false;  // a node or leaf with two parents has no single ancestor chain: no four-wide walk then
     for (uint32_t i = 0; i < d->n_nodes; i++) {
         for (uint32_t c : {d->nodes[i].left, d->nodes[i].right}) {
@@ -232,6 +234,7 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T, bool device_build) {
             if (T.nodes.size() + tris.size() >= (1u << 30)) continue;
             T.nodes.resize(T.nodes.size() + tris.size());  // zero-filled here, written by the device
             T.mesh_root4[mi] = (int32_t)job.first;
+            T.mesh_tris[mi] = job.leaves;
             T.jobs.push_back(std::move(job));
             continue;
         }
@@ -298,8 +301,12 @@ static void build_tree4(const rt_scene_desc* d, Tree4& T, bool device_build) {
             }
             T.nodes[it.idx4] = n4;
         }
-        if (usable && T.nodes.size() < (1u << 30)) T.mesh_root4[mi] = (int32_t)first;
-        else T.nodes.resize(first);
+        if (usable && T.nodes.size() < (1u << 30)) {
+            T.mesh_root4[mi] = (int32_t)first;
+            for (const SahTri& t : tris) T.mesh_tris[mi].push_back(t.leaf & ~RT_REF_LEAF);
+        } else {
+            T.nodes.resize(first);
+        }
     }
 }
 
@@ -532,10 +539,16 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
     const double rho = 0.5 * std::sqrt(cell[0] * cell[0] + cell[1] * cell[1] + cell[2] * cell[2]) * (1.0 + 1e-6) + 1e-9;
     const size_t per_lamp = (size_t)RT_CGRID * RT_CGRID * RT_CGRID;
     grid.assign(per_lamp * d->n_lights * 2, 0ull);  // per cell: [may occlude, occludes every sample]
-    for (int l = 0; l < d->n_lights; l++) {
+    // slabs (lamp, iz) are independent: host threads take them in turn
+    std::atomic<int> next_slab{0};
+    auto worker = [&]() {
+    for (;;) {
+        const int slab = next_slab.fetch_add(1);
+        if (slab >= d->n_lights * RT_CGRID) break;
+        const int l = slab / RT_CGRID, iz = slab % RT_CGRID;
         const h3 Lc = H(d->lights[l].O);
         const double Rl = lamp_r[l];
-        for (int iz = 0; iz < RT_CGRID; iz++)
+        {
             for (int iy = 0; iy < RT_CGRID; iy++)
                 for (int ix = 0; ix < RT_CGRID; ix++) {
                     const h3 A{lo[0] + (ix + 0.5) * cell[0], lo[1] + (iy + 0.5) * cell[1], lo[2] + (iz + 0.5) * cell[2]};
@@ -622,7 +635,16 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                     const size_t cell = ((size_t)l * RT_CGRID + iz) * RT_CGRID * RT_CGRID + (size_t)iy * RT_CGRID + ix;
                     grid[2 * cell] = m, grid[2 * cell + 1] = mfull;
                 }
+        }
     }
+    };
+    unsigned n_threads = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("OMP_NUM_THREADS")) n_threads = std::min<unsigned>(n_threads, (unsigned)std::max(1, std::atoi(e)));  // the host's share of cores where one is set
+    n_threads = std::max(1u, std::min(n_threads, 16u));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; t++) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
 }
 
 #endif

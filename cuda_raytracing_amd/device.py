@@ -14,17 +14,23 @@ from . import abi
 
 class DeviceScene:
     def __init__(self, host_scene, device=0, tree_builder=None):
-        """tree_builder: None = the library's default, "host" or "device" (rt_set_tree_builder)."""
+        """tree_builder: None = the library's default, "host", "device" (Morton order) or "device_sah" (rt_set_tree_builder)."""
         import torch  # noqa: F401  plumbing: loads the HIP runtime that librt_amd.so then binds to
 
         self._lib = abi.load_library()
         abi.check(self._lib.rt_init(device))
         if tree_builder is not None:
-            abi.check(self._lib.rt_set_tree_builder({"host": 0, "device": 1}[tree_builder]))
+            abi.check(self._lib.rt_set_tree_builder({"host": 0, "device": 1, "device_sah": 2}[tree_builder]))
         self.device = device
         self._h = C.c_void_p()
         abi.check(self._lib.rt_scene_create(host_scene.desc_ptr, C.byref(self._h)))
         self.host = host_scene
+
+    def check_trees(self):
+        """(number of four-wide trees, their surface-area measure); raises if a tree is broken (rt_scene_check_trees)."""
+        n, cost = C.c_int(0), C.c_double(0.0)
+        abi.check(self._lib.rt_scene_check_trees(self._h, C.byref(n), C.byref(cost)))
+        return n.value, cost.value
 
     @property
     def tree_build_ms(self):

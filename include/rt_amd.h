@@ -238,12 +238,21 @@ int rt_set_stream(void* hip_stream);
 
 /* Who builds the four-wide trees the pruned traversal walks, from the calling thread's next rt_scene_create on
  * (the setting belongs to the thread, like the render stream):
- * 0 = the host (binned surface-area heuristic, the default), 1 = the device (triangles in Morton
- * order, cut top-down where the code changes; a few ms instead of tens, somewhat slower to walk).  The
- * image does not depend on the choice.  The reference builds its one tree on the CPU
+ * 0 = the host (binned surface-area heuristic, the default),
+ * 1 = the device, triangles in Morton order, cut top-down where the code changes (about 1 ms for 100,000
+ *     triangles; frames 4-13 % slower than on the host's trees),
+ * 2 = the device, the host's surface-area algorithm run one block per node (5 ms for 33,000 triangles, 15 ms
+ *     for 103,000; frames within 1 % of those on the host's trees).
+ * The image does not depend on the choice.  The reference builds its one tree on the CPU
  * (CR/primitive.cpp:552-616, kept as it is for parity) and has no device builder; without a call
- * the environment variable RT_AMD_TREE_BUILD=device|host decides. */
+ * the environment variable RT_AMD_TREE_BUILD=host|device|device_sah decides. */
 int rt_set_tree_builder(int which);
+/* Test support: reads the scene's four-wide trees back and checks them (every triangle of a mesh under its tree
+ * exactly once, depth within the walk's stack, every child box around the exact bounds of its triangles).
+ * *trees = number of trees, *cost = their surface-area measure (sum of child-box areas over the root-box area,
+ * added up over the trees): lower = fewer box tests per ray.  RT_ERR_INVALID with a message if a tree is broken.
+ * No counterpart in the reference. */
+int rt_scene_check_trees(const rt_scene* scene, int* trees, double* cost);
 /* Device time of the last scene's tree build in ms (0 when the host built the trees). */
 double rt_scene_tree_build_ms(const rt_scene* scene);
 /* The render kernel exists in two variants that differ in how shadow rays walk the meshes (each ray on

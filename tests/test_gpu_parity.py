@@ -177,9 +177,12 @@ def test_call_cut_into_several_launches(monkeypatch):
     assert np.array_equal(canvas[y0:y0 + h, x0:x0 + w], whole[y0:y0 + h, x0:x0 + w])
 
 
+@pytest.mark.parametrize("builder", ["device", "device_sah"])
 @pytest.mark.parametrize("name,W,H,spp", [("t_icosa", 96, 72, 3), ("t_boxgrid", 96, 72, 2), ("c4_lucy", 160, 90, 2), ("c5_final", 128, 96, 1)])
-def test_trees_built_on_the_device_give_the_same_image(name, W, H, spp):
-    """The pruned walk keeps only hits the reference's own walk reaches, so any valid tree renders the same bits."""
+def test_trees_built_on_the_device_give_the_same_image(name, W, H, spp, builder):
+    """The pruned walk keeps only hits the reference's own walk reaches, so any valid tree renders the same bits.  The trees
+    themselves are read back and checked: every triangle once, depth within the walk's stack, boxes around their triangles;
+    the surface-area builder's trees must be as good as the host's by the surface-area measure."""
     from cuda_raytracing_amd.device import DeviceScene
     hs = scene(name)
     st = orc.settings(spp=spp, dof=True, focal=9.0, aperture=1.0, seed=21, flags=abi.RT_MODE_GPU_REF)
@@ -188,12 +191,17 @@ def test_trees_built_on_the_device_give_the_same_image(name, W, H, spp):
             img_h, st_h = ds.render_frame(st, W, H)
             hit_h = ds.trace_primary(st, W, H, (0, 0, W, H))[:3]
             assert ds.tree_build_ms == 0.0
-        with DeviceScene(hs, device=0, tree_builder="device") as ds:
+            trees_h, cost_h = ds.check_trees()
+        with DeviceScene(hs, device=0, tree_builder=builder) as ds:
             img_d, st_d = ds.render_frame(st, W, H)
             hit_d = ds.trace_primary(st, W, H, (0, 0, W, H))[:3]
             assert ds.tree_build_ms > 0.0
+            trees_d, cost_d = ds.check_trees()
     finally:
         abi.load_library().rt_set_tree_builder(0)
+    assert trees_d == trees_h == hs.desc.n_meshes and cost_h > 0
+    if builder == "device_sah":
+        assert cost_d <= 1.05 * cost_h, (cost_d, cost_h)
     assert np.array_equal(img_h, img_d)
     assert st_h.rays == st_d.rays and st_h.shaded_hits == st_d.shaded_hits
     for a, b in zip(hit_h, hit_d):
