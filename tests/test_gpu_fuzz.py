@@ -1,5 +1,5 @@
 """Randomised scenes against the shortcuts of the pruned render: candidate masks per lamp, umbra tests, bounding capsules,
-the candidate grid, the four-wide walk with its single-precision boxes, the shared shadow walk.  Every one of them must
+the candidate grid, the four-wide walk with its single-precision boxes over trees from all three builders, the shared shadow walk.  Every one of them must
 be invisible: the pruned image equals the reference-order image bit for bit and the ray totals are the same.  A sample of
 the scenes is also checked against the CPU oracle, so that "both GPU modes wrong in the same way" cannot pass.
 
@@ -144,7 +144,9 @@ def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
         if seed % 7 == 0:
             flags ^= abi.RT_F_MESH_RAW_DIR
         st = orc.settings(spp=SPP, dof=bool(seed % 2), focal=9.0, aperture=1.0, seed=seed + 1, flags=flags | abi.RT_F_STRICT_TRAVERSAL)
-        with DeviceScene(hs, device=0) as ds:
+        # the pruned walk's trees from each of the three builders in turn (scenes without meshes have none)
+        with DeviceScene(hs, device=0, tree_builder=("host", "device_sah", "device")[seed % 3]) as ds:
+            ds.check_trees()
             strict, ss = ds.render_frame(st, W, H)
             st.flags = flags
             fast, fs = ds.render_frame(st, W, H)
@@ -170,5 +172,6 @@ def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
         if why:
             _keep(path, seed, why)
             failures.append((seed, why))
+    abi.load_library().rt_set_tree_builder(0)
     assert not failures, f"{len(failures)} of {N_SCENES} scenes failed (scene files kept in gpurun_out/fuzz_fail_<seed>.txt): {failures[:5]}"
     assert checked_oracle >= N_SCENES // 12
