@@ -1081,6 +1081,9 @@ DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& 
             }
             default: break;
         }
+#ifdef RT_ABLATE_CLOSEST_PRIMS
+        if (RT_ABLATE_CLOSEST_PRIMS == 7 && g.type == RT_PRIM_CYLINDER && t != -1.0) t = RT_BIG_DIST;  // test paid for, hit thrown away
+#endif
         if (t < RT_BIG_DIST) {
             bool take = later_wins ? (t - best.dist < RT_EPS) : (t < best.dist);
             if (take) {
