@@ -183,6 +183,7 @@ _SIGNATURES = {
     "rt_member_pixels": (C.c_longlong, [C.c_int] * 5),
     "rt_pack_tiles": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "rt_unpack_tiles": (C.c_int, [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "rt_unpack_tiles_all": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rt_trace_primary": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p] * 5 + [C.c_int]),
     "rt_last_error": (C.c_char_p, []),
 }

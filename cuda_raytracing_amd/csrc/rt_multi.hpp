@@ -9,61 +9,60 @@
 #define RT_MULTI_HPP
 #include <thread>
 
-// Pixel k of a member's packed buffer: its tiles in row-major tile order, each tile row by row (edge tiles are narrower /
-// shorter).  One thread per pixel of the member's tiles; `tile_first[j]` = packed index of the first pixel of the
-// member's j-th tile, found by binary search.
+// A member's packed buffer: its tiles in row-major tile order, each tile row by row (edge tiles are narrower / shorter).
+// One block per tile of the member; its first thread finds where the tile starts in the packed buffer.
 struct PackParams {
     int32_t tex_w, tex_h, tile, part, n_parts, tiles_x, n_tiles_total;
     uint32_t n_pixels;  // of this member
 };
-DEV void pack_locate(const PackParams& Q, uint32_t k, uint32_t& image_index) {
-    // Tiles of a member are t = part, part + n_parts, ...; all but those in the last column / last row are tile x tile.
-    // Walk whole tile rows first (each row of tiles holds the same number of the member's pixels except the last), then
-    // the tiles of the row.  Rows of tiles are few (< 1100 at 32768 pixels), so a linear walk over them is cheap
-    // compared with the copy itself, and it needs no table in memory.
+// packed index of the first pixel of tile t (which must belong to member `part`)
+DEV uint32_t pack_tile_start(const PackParams& Q, int part, int t) {
+    // Whole tile rows first (each holds the same number of the member's pixels except where the member owns the narrower
+    // last column, and the last row is shorter), then the member's tiles to the left in the tile's own row.  Rows of tiles
+    // are few (< 4100 at 32768 pixels and 8-pixel tiles), and the walk runs once per tile.
     const int tile = Q.tile, tx = Q.tiles_x;
     const int ty = (Q.tex_h + tile - 1) / tile;
     const int last_w = Q.tex_w - (tx - 1) * tile, last_h = Q.tex_h - (ty - 1) * tile;
-    uint32_t rest = k;
-    for (int j = 0; j < ty; j++) {
+    const int tj = t / tx, ti = t - tj * tx;
+    uint32_t start = 0;
+    for (int j = 0; j <= tj; j++) {
         const int th = j == ty - 1 ? last_h : tile;
         // member tiles in row j: columns i with (j * tx + i) % n_parts == part
-        int i0 = (Q.part - (int)(((long long)j * tx) % Q.n_parts) + Q.n_parts) % Q.n_parts;
+        const int i0 = (part - (int)(((long long)j * tx) % Q.n_parts) + Q.n_parts) % Q.n_parts;
         if (i0 >= tx) continue;
+        if (j == tj) {
+            start += (uint32_t)th * (uint32_t)tile * (uint32_t)((ti - i0) / Q.n_parts);  // none of those is the last column
+            break;
+        }
         const int cnt = (tx - 1 - i0) / Q.n_parts + 1;
         const bool has_last = (i0 + (cnt - 1) * Q.n_parts) == tx - 1;
-        const uint32_t row_pixels = (uint32_t)th * (uint32_t)((cnt - (has_last ? 1 : 0)) * tile + (has_last ? last_w : 0));
-        if (rest >= row_pixels) {
-            rest -= row_pixels;
-            continue;
-        }
-        // inside tile row j
-        const uint32_t full = (uint32_t)th * (uint32_t)tile;
-        int c = (int)(rest / full);
-        if (c >= cnt) c = cnt - 1;  // only the last tile of the row can be narrower
-        rest -= (uint32_t)c * full;
-        const int i = i0 + c * Q.n_parts;
-        const int tw = i == tx - 1 ? last_w : tile;
-        const int ry = (int)(rest / (uint32_t)tw), rx = (int)(rest - (uint32_t)ry * (uint32_t)tw);
-        image_index = (uint32_t)(j * tile + ry) * (uint32_t)Q.tex_w + (uint32_t)(i * tile + rx);
-        return;
+        start += (uint32_t)th * (uint32_t)((cnt - (has_last ? 1 : 0)) * tile + (has_last ? last_w : 0));
     }
-    image_index = 0xFFFFFFFFu;
+    return start;
 }
-__global__ __launch_bounds__(256) void pack_tiles_kernel(PackParams Q, const uint32_t* image, uint32_t* packed) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= Q.n_pixels) return;
-    uint32_t at;
-    pack_locate(Q, k, at);
-    if (at != 0xFFFFFFFFu) packed[k] = image[at];
+// UNPACK = false: frame -> packed, true: packed -> frame.  blockIdx.x = which of the member's tiles, blockIdx.y = which member
+// (first_part + y; its pack starts at packed + y * stride_words).
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void tiles_copy_kernel(PackParams Q, int first_part, unsigned long long stride_words, const uint32_t* src, uint32_t* dst) {
+    const int part = first_part + (int)blockIdx.y;
+    const long long t64 = (long long)part + (long long)blockIdx.x * Q.n_parts;
+    if (t64 >= Q.n_tiles_total) return;
+    const int t = (int)t64;
+    __shared__ uint32_t s_start;
+    if (threadIdx.x == 0) s_start = pack_tile_start(Q, part, t);
+    __syncthreads();
+    const int tj = t / Q.tiles_x, ti = t - tj * Q.tiles_x;
+    const int x0 = ti * Q.tile, y0 = tj * Q.tile;
+    const uint32_t w = (uint32_t)min(Q.tile, Q.tex_w - x0), h = (uint32_t)min(Q.tile, Q.tex_h - y0);
+    const size_t pack0 = (size_t)blockIdx.y * stride_words + s_start;
+    for (uint32_t p = threadIdx.x; p < w * h; p += 256u) {
+        const uint32_t ry = p / w, rx = p - ry * w;
+        const size_t at = (size_t)(y0 + (int)ry) * (size_t)Q.tex_w + (size_t)(x0 + (int)rx);
+        if (UNPACK) dst[at] = src[pack0 + p];
+        else dst[pack0 + p] = src[at];
+    }
 }
-__global__ __launch_bounds__(256) void unpack_tiles_kernel(PackParams Q, const uint32_t* packed, uint32_t* image) {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k >= Q.n_pixels) return;
-    uint32_t at;
-    pack_locate(Q, k, at);
-    if (at != 0xFFFFFFFFu) image[at] = packed[k];
-}
+#define RT_UNPACK_PARTS 65535  // members one launch can serve (grid y)
 
 static uint64_t member_pixels(int tex_w, int tex_h, int tile, int part, int n_parts) {
     const int tx = (tex_w + tile - 1) / tile, ty = (tex_h + tile - 1) / tile;
@@ -86,9 +85,9 @@ static int pack_common(bool unpack, const void* src, void* dst, int tex_w, int t
     if (n_out) *n_out = n;
     if (n == 0) return RT_OK;
     if (!src || !dst) return rt_fail(RT_ERR_INVALID, "null buffer");
-    const dim3 g((unsigned)((n + 255) / 256)), t(256);
-    if (unpack) hipLaunchKernelGGL(unpack_tiles_kernel, g, t, 0, g_stream, Q, (const uint32_t*)src, (uint32_t*)dst);
-    else hipLaunchKernelGGL(pack_tiles_kernel, g, t, 0, g_stream, Q, (const uint32_t*)src, (uint32_t*)dst);
+    const dim3 g((unsigned)((Q.n_tiles_total - part + n_parts - 1) / n_parts)), t(256);  // the member's tiles
+    if (unpack) hipLaunchKernelGGL(tiles_copy_kernel<true>, g, t, 0, g_stream, Q, part, 0ull, (const uint32_t*)src, (uint32_t*)dst);
+    else hipLaunchKernelGGL(tiles_copy_kernel<false>, g, t, 0, g_stream, Q, part, 0ull, (const uint32_t*)src, (uint32_t*)dst);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -104,13 +103,38 @@ extern "C" int rt_unpack_tiles(const uint8_t* packed_device, int tex_w, int tex_
     return pack_common(true, packed_device, image_device, tex_w, tex_h, tile, part, n_parts, nullptr);
 }
 
+extern "C" int rt_unpack_tiles_all(const uint8_t* packed_device, size_t stride_bytes, int tex_w, int tex_h, int tile, int first_part, int n_parts,
+                                   uint8_t* image_device) {
+    if (tex_w <= 0 || tex_h <= 0 || tex_w > 32768 || tex_h > 32768 || tile <= 0 || (tile & 7) || n_parts <= 0 || first_part < 0 || first_part > n_parts ||
+        (stride_bytes & 3))
+        return rt_fail(RT_ERR_INVALID, "tile must be a positive multiple of 8, 0 <= first_part <= n_parts, stride a multiple of 4, image size in range");
+    if (first_part == n_parts) return RT_OK;
+    if (!packed_device || !image_device) return rt_fail(RT_ERR_INVALID, "null buffer");
+    PackParams Q;
+    Q.tex_w = tex_w, Q.tex_h = tex_h, Q.tile = tile, Q.part = first_part, Q.n_parts = n_parts;
+    Q.tiles_x = (tex_w + tile - 1) / tile;
+    Q.n_tiles_total = Q.tiles_x * ((tex_h + tile - 1) / tile);
+    Q.n_pixels = 0;
+    for (int p = first_part; p < n_parts; p++)
+        if (member_pixels(tex_w, tex_h, tile, p, n_parts) * 4 > stride_bytes) return rt_fail(RT_ERR_INVALID, "rt_unpack_tiles_all: a pack is longer than the stride");
+    const unsigned tiles_most = (unsigned)((Q.n_tiles_total - first_part + n_parts - 1) / n_parts);  // the first of the parts owns the most tiles
+    if (tiles_most == 0) return RT_OK;
+    for (int p0 = first_part; p0 < n_parts; p0 += RT_UNPACK_PARTS) {
+        const int here = std::min(RT_UNPACK_PARTS, n_parts - p0);
+        hipLaunchKernelGGL(tiles_copy_kernel<true>, dim3(tiles_most, (unsigned)here), dim3(256), 0, g_stream, Q, p0, (unsigned long long)(stride_bytes / 4),
+                           (const uint32_t*)packed_device + (size_t)(p0 - first_part) * (stride_bytes / 4), (uint32_t*)image_device);
+        HIPCHK(hipGetLastError());
+    }
+    return RT_OK;
+}
+
 // ---- a scene on several GPUs ---------------------------------------------------------------------------------------
 struct rt_scene_group {
     std::vector<int> devices;
     std::vector<rt_scene*> scenes;     // one replica per member
     std::vector<uint8_t*> image;       // per member: its frame (device memory on its GPU); member 0's is the assembled frame
     std::vector<uint8_t*> packed;      // per member > 0: its packed tiles on its own GPU
-    std::vector<uint8_t*> landing;     // per member > 0: where those arrive on the first GPU
+    std::vector<uint8_t*> landing;     // per member > 0: where those arrive on the first GPU (slices of one block, landing[1] is its start)
     size_t image_bytes = 0, packed_bytes = 0;
     std::vector<float> member_ms;      // kernel time of every member in the last frame
 };
@@ -133,8 +157,7 @@ extern "C" void rt_scene_group_destroy(rt_scene_group* g) {
         if (k < g->packed.size() && g->packed[k]) (void)hipFree(g->packed[k]);
     }
     if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
-    for (uint8_t* p : g->landing)
-        if (p) (void)hipFree(p);
+    if (g->landing.size() > 1 && g->landing[1]) (void)hipFree(g->landing[1]);
     delete g;
 }
 
@@ -192,10 +215,8 @@ static int group_buffers(rt_scene_group* g, int tex_w, int tex_h, int tile) {
         g->image[k] = g->packed[k] = nullptr;
     }
     HIPCHK(hipSetDevice(g->devices[0]));
-    for (int k = 0; k < n; k++) {
-        if (g->landing[k]) (void)hipFree(g->landing[k]);
-        g->landing[k] = nullptr;
-    }
+    if (n > 1 && g->landing[1]) (void)hipFree(g->landing[1]);
+    for (int k = 0; k < n; k++) g->landing[k] = nullptr;
     g->image_bytes = g->packed_bytes = 0;
     for (int k = 0; k < n; k++) {
         HIPCHK(hipSetDevice(g->devices[k]));
@@ -203,8 +224,10 @@ static int group_buffers(rt_scene_group* g, int tex_w, int tex_h, int tile) {
         if (k > 0 && pk) HIPCHK(hipMalloc(&g->packed[k], pk));
     }
     HIPCHK(hipSetDevice(g->devices[0]));
-    for (int k = 1; k < n; k++)
-        if (pk) HIPCHK(hipMalloc(&g->landing[k], pk));
+    if (n > 1 && pk) {
+        HIPCHK(hipMalloc(&g->landing[1], pk * (size_t)(n - 1)));
+        for (int k = 2; k < n; k++) g->landing[k] = g->landing[1] + pk * (size_t)(k - 1);
+    }
     g->image_bytes = bytes, g->packed_bytes = pk;
     return RT_OK;
 }
@@ -253,8 +276,8 @@ extern "C" int rt_render_frame_multi(rt_scene_group* g, const rt_settings* st, i
         if (codes[k]) return rt_fail(codes[k], "GPU " + std::to_string(g->devices[k]) + ": " + messages[k]);
     // the first GPU writes the arrived tiles into its frame
     HIPCHK(hipSetDevice(g->devices[0]));
-    for (int k = 1; k < n; k++) {
-        rc = pack_common(true, g->landing[k], g->image[0], tex_w, tex_h, tile, k, n, nullptr);
+    if (n > 1 && g->packed_bytes) {
+        rc = rt_unpack_tiles_all(g->landing[1], g->packed_bytes, tex_w, tex_h, tile, 1, n, g->image[0]);
         if (rc) return rc;
     }
     const size_t bytes = (size_t)tex_w * tex_h * 4;

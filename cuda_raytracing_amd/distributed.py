@@ -56,7 +56,9 @@ class FrameGather:
         self.max_count = max(self.counts)
         # RGBA8 pixels travel as one int32 each; dist.gather wants equal sizes, so every pack has the largest part's size
         self.pack = torch.zeros(self.max_count, dtype=torch.int32, device=device)
-        self.recv = [torch.zeros(self.max_count, dtype=torch.int32, device=device) for _ in range(world)] if rank == 0 else None
+        # rank 0 receives into the rows of one buffer, so that one kernel can write all peers' tiles into the frame
+        self._landing = torch.zeros((world, self.max_count), dtype=torch.int32, device=device) if rank == 0 else None
+        self.recv = [self._landing[r] for r in range(world)] if rank == 0 else None
 
     def _pack(self, image):
         if self.on_gpu:
@@ -80,6 +82,10 @@ class FrameGather:
         dist.gather(self.pack, self.recv if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
-        for r in range(1, self.world):
-            self._unpack(r, image)
+        if self.on_gpu:
+            abi.check(self._lib.rt_unpack_tiles_all(self.recv[1].data_ptr(), self.max_count * 4, self.width, self.height, self.tile, 1, self.world,
+                                                    image.data_ptr()))
+        else:
+            for r in range(1, self.world):
+                self._unpack(r, image)
         return image

@@ -335,6 +335,10 @@ int rt_render_frame_multi(rt_scene_group* group, const rt_settings* settings, in
 long long rt_member_pixels(int tex_w, int tex_h, int tile, int part, int n_parts);
 int rt_pack_tiles(const uint8_t* image_device, int tex_w, int tex_h, int tile, int part, int n_parts, uint8_t* packed_device);
 int rt_unpack_tiles(const uint8_t* packed_device, int tex_w, int tex_h, int tile, int part, int n_parts, uint8_t* image_device);
+/* rt_unpack_tiles for the packs of parts first_part .. n_parts-1 in one launch: the pack of part p starts at
+ * packed_device + (p - first_part) * stride_bytes (what a gather into one buffer leaves on the receiving GPU). */
+int rt_unpack_tiles_all(const uint8_t* packed_device, size_t stride_bytes, int tex_w, int tex_h, int tile, int first_part,
+                        int n_parts, uint8_t* image_device);
 
 /* Debug/parity: trace only the primary ray (sample 0, no jitter, no depth of field) of every
  * pixel of the rectangle.  hit_prim[i] = primitive index or -1, hit_t[i] = distance,

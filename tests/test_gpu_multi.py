@@ -41,6 +41,18 @@ def test_pack_and_unpack_kernels_match_the_packed_order(W, H, tile, world):
         abi.check(lib.rt_unpack_tiles(packed.data_ptr(), W, H, tile, part, world, rebuilt.data_ptr()))
     torch.cuda.synchronize()
     assert total == W * H and torch.equal(rebuilt, dev)
+    # all packs but the first part's in the rows of one buffer, written into the frame by one launch
+    most = max(int(lib.rt_member_pixels(W, H, tile, part, world)) for part in range(world))
+    landing = torch.full((world, most + 3), -1, dtype=torch.int32, device="cuda")
+    for part in range(1, world):
+        abi.check(lib.rt_pack_tiles(dev.data_ptr(), W, H, tile, part, world, landing[part].data_ptr()))
+    again = torch.zeros_like(dev)
+    abi.check(lib.rt_pack_tiles(dev.data_ptr(), W, H, tile, 0, world, landing[0].data_ptr()))
+    abi.check(lib.rt_unpack_tiles(landing[0].data_ptr(), W, H, tile, 0, world, again.data_ptr()))
+    abi.check(lib.rt_unpack_tiles_all(landing[1].data_ptr(), (most + 3) * 4, W, H, tile, 1, world, again.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(again, dev)
+    assert lib.rt_unpack_tiles_all(landing[1].data_ptr(), 8, W, H, tile, 1, world, again.data_ptr()) != 0  # stride shorter than a pack
 
 
 @pytest.mark.parametrize("members", [[0], [0, 0], [0, 0, 0, 0, 0]])
