@@ -18,7 +18,8 @@ from helpers import ROOT
 
 pytestmark = pytest.mark.gpu
 
-N_SCENES = 400
+N_SCENES = int(os.environ.get("RT_FUZZ_SCENES", "400"))      # a soak run sets these two: other seeds, more of them
+FIRST_SEED = int(os.environ.get("RT_FUZZ_FIRST_SEED", "0"))
 W, H, SPP = 64, 48, 2
 
 
@@ -135,7 +136,9 @@ def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
     from cuda_raytracing_amd.device import DeviceScene
     failures = []
     checked_oracle = 0
-    for seed in range(N_SCENES):
+    for seed in range(FIRST_SEED, FIRST_SEED + N_SCENES):
+        if seed % 100 == 0:
+            print(f"fuzz: seed {seed}, {len(failures)} failures so far", flush=True)  # visible with -s: a soak run must not look hung
         path = make_scene(seed, str(tmp_path))
         hs = HostScene(path, asset_dir=os.path.join(ROOT, "assets"))
         flags = abi.RT_MODE_GPU_REF if seed % 3 else abi.RT_MODE_CPU_REF
