@@ -16,7 +16,7 @@ while a:
     else:
         extra.append(x)
 cs = os.path.join(ROOT, "cuda_raytracing_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-gpu-rdc",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-fno-gpu-rdc",
        "-I" + os.path.join(ROOT, "include"), "-I" + cs, os.path.join(cs, "rt_device.hip"), os.path.join(cs, "host_scene.cpp"),
        os.path.join(cs, "rt_error.cpp"), "-Rpass-analysis=kernel-resource-usage", "-o", out] + extra
 p = subprocess.run(cmd, capture_output=True, text=True)

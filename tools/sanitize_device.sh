@@ -9,7 +9,7 @@ if [ "$1" = "build" ]; then
   mkdir -p $OUT
   SAN="-fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -g"
   C=cuda_raytracing_amd/csrc
-  hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC -shared -ffp-contract=off -fno-gpu-rdc -Wno-unused-function $SAN -Iinclude -I$C \
+  hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -disable-machine-licm -fno-gpu-rdc -Wno-unused-function $SAN -Iinclude -I$C \
     $C/rt_device.hip $C/host_scene.cpp $C/rt_error.cpp -o $OUT/librt_amd.so
   hipcc -O1 -std=c++17 $SAN -Iinclude tools/sanitize/device_paths.cpp -L$OUT -lrt_amd '-Wl,-rpath,$ORIGIN' -o $OUT/device_paths
 elif [ "$1" = "run" ]; then
