@@ -66,9 +66,9 @@ DEV uint32_t take_slots(uint32_t* counter, uint32_t chunk, uint32_t n, uint32_t&
 // ---- path kernel -----------------------------------------------------------------------------------------------------
 // CalnDiffusion without the shadow rays: the surface colour, N.L per lamp and, per lamp, what is known about the shadow
 // without tracing (light_candidates) go into the node record; where rays are needed, a job goes into that lamp's queue.
-DEV void diffusion_defer(const RenderParams& P, const DeferParams& D, const DevShade* shade, bool need, const Hit& h, uint32_t& draw, uint32_t pixel,
+DEV void diffusion_defer(RPREF P, const DeferParams& D, const DevShade* shade, bool need, const Hit& h, uint32_t& draw, uint32_t pixel,
                          uint32_t smp, Counters& ctr, NodeRec* rec, uint32_t node, bool node_ok, uint32_t* job_chunk) {
-    const DevScene& sc = P.sc;
+    SCREF sc = P.sc;
     const int lane = lane_id();
     if (need) {
         const DevShade& m = shade[h.prim];
@@ -127,8 +127,8 @@ DEV void diffusion_defer(const RenderParams& P, const DeferParams& D, const DevS
 }
 
 // All paths of a launch, as trace_stream traces them, minus everything that needs a colour.
-DEV void trace_defer(const RenderParams& P, const DeferParams& D, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* job_chunk) {
-    const DevScene& sc = P.sc;
+DEV void trace_defer(RPREF P, const DeferParams& D, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* job_chunk) {
+    SCREF sc = P.sc;
     // frame k = the hit at depth k+1 whose refraction waits for the reflection subtree (both coefficients non-zero)
     double f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3];
     uint32_t f_prim[RT_MAX_DEPTH];  // primitive index | stage bits << 28
@@ -172,13 +172,13 @@ DEV void trace_defer(const RenderParams& P, const DeferParams& D, const DevShade
                 if ((slot & 7u) < rec.w && (slot >> 3) < rec.h) {
                     const int px = rec.x0 + (int)(slot & 7u), py = rec.y0 + (int)(slot >> 3);
                     int x, y;
-                    map_pixel(P, px, py, x, y);
+                    map_pixel(P.flags, P.tex_w, P.tex_h, sc.cam_w, sc.cam_h, px, py, x, y);
                     const d3 dc = unit(emit(sc, x, y));
                     pixel = (uint32_t)py * (uint32_t)P.tex_w + (uint32_t)px;
                     smp = s;
                     my_path = (blk * (uint32_t)P.spp + s) * 64u + slot;
                     sp = 0, draw = 0, tracing = true, cur_node = RT_REF_END;
-                    o = sc.camO, d = dc;
+                    o = D3(sc.camO), d = dc;
                     if (P.spp == 1) {
                         if (!(P.flags & RT_F_NORMALIZE_PRIMARY)) d = emit(sc, x, y);
                     } else {
@@ -191,13 +191,13 @@ DEV void trace_defer(const RenderParams& P, const DeferParams& D, const DevShade
                         if (P.flags & RT_F_NORMALIZE_PRIMARY) d = unit(d);
                     }
                     if (P.dof) {  // modifyRayForDepthOfField, CR/RayTracer.cu:31-38
-                        const d3 focal = sc.camO + dc * P.focal;
+                        const d3 focal = D3(sc.camO) + dc * P.focal;
                         float fa, fb;
                         frand_pair(P.k0, P.k1, pixel, smp, draw, fa, fb);
                         draw += 2;
                         double rx = (fa - 0.5) * P.aperture / 10.0;
                         double ry = (fb - 0.5) * P.aperture / 10.0;
-                        o = o + (sc.camDx * rx + sc.camDy * ry);
+                        o = o + (D3(sc.camDx) * rx + D3(sc.camDy) * ry);
                         d = unit(focal - o);
                     }
                 }
@@ -225,7 +225,7 @@ DEV void trace_defer(const RenderParams& P, const DeferParams& D, const DevShade
             if (h.prim < 0) {
                 d3 c = unit(d);
                 double t = 0.5 * (((P.flags & RT_F_SKY_Y) ? c.y : c.z) + 1.0);
-                result = clamp1(sc.bg_bottom * (1.0 - t) + sc.bg_top * t);
+                result = clamp1(D3(sc.bg_bottom) * (1.0 - t) + D3(sc.bg_top) * t);
             } else if (shade[h.prim].is_light) {
                 result = clamp1(D3(shade[h.prim].color));
             } else {
@@ -334,7 +334,7 @@ DEV void trace_defer(const RenderParams& P, const DeferParams& D, const DevShade
 #define RT_SHADOW_WAVES 4
 #endif
 
-DEV void flush_counters(const RenderParams& P, Counters& ctr) {
+DEV void flush_counters(RPREF P, Counters& ctr) {
     const int lane = lane_id();
     unsigned long long v[CTR_COUNT] = {ctr.rays_secondary, ctr.rays_shadow, ctr.nodes, ctr.tris, ctr.shaded, ctr.texfetch, 0ull};
 #pragma unroll
@@ -346,7 +346,8 @@ DEV void flush_counters(const RenderParams& P, Counters& ctr) {
 }
 
 template <int SHADE_CAP>
-__global__ __launch_bounds__(256, RT_PATH_WAVES) void path_kernel(RenderParams P, DeferParams D) {
+__global__ __launch_bounds__(256, RT_PATH_WAVES) void path_kernel(RenderParams, DeferParams D) {
+    RPREF P = KERNARG(RenderParams);
     const int lane = lane_id();
     __shared__ uint32_t s_stack[4 * RT_STACK * 64];
     uint32_t* stk = s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
@@ -374,9 +375,10 @@ __global__ __launch_bounds__(256, RT_PATH_WAVES) void path_kernel(RenderParams P
 // Every job of every lamp: lane = one light sample of one shaded point.  The rays of a job sit in neighbouring lanes; the
 // first lane of each run adds the run's visible samples to the node's count (integer adds: the order does not matter).
 template <bool SHARE>
-__global__ __launch_bounds__(256, RT_SHADOW_WAVES) void shadow_kernel(RenderParams P, DeferParams D) {
+__global__ __launch_bounds__(256, RT_SHADOW_WAVES) void shadow_kernel(RenderParams, DeferParams D) {
+    RPREF P = KERNARG(RenderParams);
     if (*D.overflow) return;
-    const DevScene& sc = P.sc;
+    SCREF sc = P.sc;
     const int lane = lane_id();
     __shared__ uint32_t s_stack[4 * RT_STACK * 64];
     uint32_t* stk = s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
@@ -441,9 +443,10 @@ __global__ __launch_bounds__(256, RT_SHADOW_WAVES) void shadow_kernel(RenderPara
 // lane = path.  Walks the path's nodes from the last to the first; a node's children (reflection subtree first, then
 // refraction subtree, in the recursion's order) lie after it, so walking backwards meets the refraction subtree's root
 // first and the reflection subtree's root last: their colours wait on a small stack, reflection on top.
-__global__ __launch_bounds__(256) void fold_kernel(RenderParams P, DeferParams D) {
+__global__ __launch_bounds__(256) void fold_kernel(RenderParams, DeferParams D) {
+    RPREF P = KERNARG(RenderParams);
     if (*D.overflow) return;
-    const DevScene& sc = P.sc;
+    SCREF sc = P.sc;
     for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < P.n_paths; p += gridDim.x * 256u) {
         uint32_t idx = D.last_node[p];
         if (idx == RT_REF_END) continue;

@@ -74,6 +74,9 @@ struct RenderParams {
     double* path_out;  // n_paths * 3 doubles: colours of finished paths
     unsigned long long* counters;
 };
+#define RPREF const RenderParams RT_CONST&
+// the kernel's first argument, read in place (the by-value parameter of the same type is what the launch fills in)
+#define KERNARG(T) (*(const T RT_CONST*)(unsigned long long)__builtin_amdgcn_kernarg_segment_ptr())
 #ifndef RT_LAUNCH_PATHS
 #define RT_LAUNCH_PATHS (1ull << 28)  // most paths of one launch (their colours take 24 bytes each: 6.4 GB); larger calls are cut into several launches
 #endif
@@ -91,16 +94,16 @@ enum { CTR_SECONDARY = 0, CTR_SHADOW, CTR_NODES, CTR_TRIS, CTR_SHADED, CTR_TEXFE
        CTR_U_SHADOW_SLOTS = CTR_COUNT, CTR_U_SHADOW_ITEMS, CTR_U_TRACE_SLOTS, CTR_U_TRACE_ACTIVE, CTR_U_PROBES, CTR_ALL = CTR_U_PROBES + 12 };
 
 // ---- camera: CR/RayTracer.cu:52-61, CR/camera.cpp:57-59 -------------------------------------------
-DEV d3 emit(const DevScene& sc, double x, double y) {
-    return sc.camN + sc.camDy * (2 * y / sc.cam_h - 1) + sc.camDx * (2 * x / sc.cam_w - 1);
+DEV d3 emit(SCREF sc, double x, double y) {
+    return D3(sc.camN) + D3(sc.camDy) * (2 * y / sc.cam_h - 1) + D3(sc.camDx) * (2 * x / sc.cam_w - 1);
 }
-DEV void map_pixel(const RenderParams& P, int sx, int sy, int& x, int& y) {
-    if (P.flags & RT_F_PIXEL_MAP_TRUNC) {
-        x = (int)((double)sx / P.tex_w * P.sc.cam_w);
-        y = (int)((double)sy / P.tex_h * P.sc.cam_h);
+DEV void map_pixel(uint32_t flags, int tex_w, int tex_h, int cam_w, int cam_h, int sx, int sy, int& x, int& y) {
+    if (flags & RT_F_PIXEL_MAP_TRUNC) {
+        x = (int)((double)sx / tex_w * cam_w);
+        y = (int)((double)sy / tex_h * cam_h);
     } else {
-        x = (int)(((long long)sx * P.sc.cam_w) / P.tex_w);
-        y = (int)(((long long)sy * P.sc.cam_h) / P.tex_h);
+        x = (int)(((long long)sx * cam_w) / tex_w);
+        y = (int)(((long long)sy * cam_h) / tex_h);
     }
 }
 DEV d3 clamp1(d3 c) {  // Color::Confine, CR/color.cpp:53-57 / CR/Scene.cu:54-56
@@ -116,12 +119,24 @@ DEV uint32_t to_u8(double c) {
     return (uint32_t)(int)v;
 }
 
+// `pp` = the address of the launch parameters again, as a value the compiler knows nothing about: loads through it cannot be
+// moved above this point, so what a stage needs of the parameters is loaded (scalar loads, cached) when the stage begins
+#define RT_FRESH()                   \
+    do {                             \
+        pp = &P_in;                  \
+        asm volatile("" : "+s"(pp)); \
+    } while (0)
+
 // ---- CalnDiffusion for every lane that needs it, shadow rays dealt over the wave ---------------
 // CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
 template <bool STRICT, bool SHARE>
-DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
+DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
                       uint32_t pixel, uint32_t smp, Counters& ctr, uint32_t* stk, uint32_t* xch) {
-    const DevScene& sc = P.sc;
+    const RenderParams RT_CONST* pp;
+    RT_FRESH();
+#define P (*pp)
+#define sc (pp->sc)
+#define L (LIGHTS(sc)[l])  // the lamp's record, read where it lies
     const int lane = lane_id();
     d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
     double m_diff = 0.0, m_spec = 0.0;
@@ -137,7 +152,7 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
     RT_LAP(ctr, PF_SHADE_SETUP);
     uint32_t off = 0;
     for (int l = 0; l < sc.n_lights; l++) {
-        const rt_light RT_CONST& L = LIGHTS(sc)[l];
+        RT_FRESH();
         const bool point = L.type == RT_LIGHT_POINT;
         const int n_l = point ? 1 : sc.shade_n;
         // Which lanes have shadow rays worth tracing for this lamp.  In reference-order mode all of
@@ -211,6 +226,7 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
             }
 #endif
             RT_LAP(ctr, PF_CHUNK_SHFL);
+            RT_FRESH();
             d3 target = d3{L.O.x, L.O.y, L.O.z};
             if (act) {
 #ifdef RT_ABLATE_RNG
@@ -245,6 +261,7 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
 #ifdef RT_PAIR_STATS
         if (heavy) { ctr.u[7] += 1; ctr.u[9] += (cnt == n_l) ? 1u : 0u; ctr.u[11] += (cnt == 0) ? 1u : 0u; }
 #endif
+        RT_FRESH();
         if (need && dt > RT_EPS) {
             double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
             if (!(shade < RT_EPS)) {
@@ -266,6 +283,9 @@ DEV d3 diffusion_coop(const RenderParams& P, const DevShade* shade, unsigned lon
     }
     if (need) draw += off;
     return ret;
+#undef P
+#undef sc
+#undef L
 }
 
 // ---- one path per lane: CR/Scene.cu:23-58 + CR/Scene_Material.cu:68-118 as a loop ----------------
@@ -281,8 +301,14 @@ DEV uint32_t div_by(uint32_t n, uint32_t d, double inv) {
 // All paths of a launch.  The wave keeps up to 64 paths in flight, one per lane; lanes whose path has ended wait
 // until enough of them are idle, then take the next unstarted paths of the launch together ("path regeneration").
 template <bool STRICT, bool SHARE>
-DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* xch) {
-    const DevScene& sc = P.sc;
+DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* xch) {
+    // The launch parameters and the scene record are read from the kernel-argument segment where they are needed, through a
+    // pointer the compiler has to take as new at the start of every stage (RT_FRESH): otherwise all ~100 words of them are
+    // loaded at the kernel's entry, kept for its whole life, and - there being no scalar registers for that - parked in lanes
+    // of vector registers, from where every use fetches them with a vector instruction.
+    const RenderParams RT_CONST* pp = &P_in;
+#define P (*pp)
+#define sc (pp->sc)
     // frame k = the hit at depth k+1 that is waiting for a child ray to return
     double f_acc[RT_MAX_DEPTH][3], f_C[RT_MAX_DEPTH][3], f_N[RT_MAX_DEPTH][3], f_V[RT_MAX_DEPTH][3], f_dist[RT_MAX_DEPTH];
     uint32_t f_prim[RT_MAX_DEPTH];  // primitive index | stage bits << 28
@@ -295,12 +321,13 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
     uint32_t range = blockIdx.x & 7u, ranges_done = 0;
     uint32_t pixel = 0, smp = 0, draw = 0, no_log = 0;
     d3 o = D3(0, 0, 0), d = D3(0, 0, 1);
-    const uint32_t block_paths = 64u * (uint32_t)P.spp;
 
     for (;;) {
         // ---- idle lanes start the next paths of the launch (CR/RayTracer.cu:52-72) ----
         const unsigned long long idle = __ballot(!tracing);
         if (!drained && (__popcll(idle) >= RT_REFILL_MIN || idle == ~0ull)) {
+            RT_FRESH();
+            const uint32_t block_paths = 64u * (uint32_t)P.spp;
             const uint32_t n_new = (uint32_t)__popcll(idle);
             uint32_t base = 0, end = 0;
             for (;;) {  // this wave's range first; the ranges after it once theirs are used up
@@ -326,13 +353,13 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
                 if ((slot & 7u) < rec.w && (slot >> 3) < rec.h) {
                     const int px = rec.x0 + (int)(slot & 7u), py = rec.y0 + (int)(slot >> 3);
                     int x, y;
-                    map_pixel(P, px, py, x, y);
+                    map_pixel(P.flags, P.tex_w, P.tex_h, sc.cam_w, sc.cam_h, px, py, x, y);
                     const d3 dc = unit(emit(sc, x, y));
                     pixel = (uint32_t)py * (uint32_t)P.tex_w + (uint32_t)px;
                     smp = s;
                     my_path = (blk * (uint32_t)P.spp + s) * 64u + slot;
                     sp = 0, draw = 0, tracing = true;
-                    o = sc.camO, d = dc;
+                    o = D3(sc.camO), d = dc;
                     if (P.spp == 1) {
                         if (!(P.flags & RT_F_NORMALIZE_PRIMARY)) d = emit(sc, x, y);
                     } else {
@@ -345,13 +372,13 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
                         if (P.flags & RT_F_NORMALIZE_PRIMARY) d = unit(d);
                     }
                     if (P.dof) {  // modifyRayForDepthOfField, CR/RayTracer.cu:31-38
-                        const d3 focal = sc.camO + dc * P.focal;
+                        const d3 focal = D3(sc.camO) + dc * P.focal;
                         float fa, fb;
                         frand_pair(P.k0, P.k1, pixel, smp, draw, fa, fb);
                         draw += 2;
                         double rx = (fa - 0.5) * P.aperture / 10.0;
                         double ry = (fb - 0.5) * P.aperture / 10.0;
-                        o = o + (sc.camDx * rx + sc.camDy * ry);
+                        o = o + (D3(sc.camDx) * rx + D3(sc.camDy) * ry);
                         d = unit(focal - o);
                     }
                 }
@@ -371,13 +398,14 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
         ctr.u_trace_slots++;
         ctr.u_trace_active += (tracing && sp + 1 <= RT_MAX_DEPTH) ? 1u : 0u;
 #endif
+        RT_FRESH();
         if (tracing && sp + 1 <= RT_MAX_DEPTH) {
             if (sp > 0) ctr.rays_secondary++;
             h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log, stk, RT_SHARE_CLOSEST && SHARE ? xch : nullptr);
             if (h.prim < 0) {
                 d3 c = unit(d);
                 double t = 0.5 * (((P.flags & RT_F_SKY_Y) ? c.y : c.z) + 1.0);
-                result = clamp1(sc.bg_bottom * (1.0 - t) + sc.bg_top * t);
+                result = clamp1(D3(sc.bg_bottom) * (1.0 - t) + D3(sc.bg_top) * t);
             } else if (shade[h.prim].is_light) {
                 result = clamp1(D3(shade[h.prim].color));
             } else {
@@ -395,8 +423,10 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
         }
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);
+        RT_FRESH();
         if (mask != 0ull) local = diffusion_coop<STRICT, SHARE>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk, xch);
 
+        RT_FRESH();
         if (tracing) {
             bool have_result = !surface;
             if (surface) {
@@ -497,6 +527,8 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
         }
         RT_LAP(ctr, PF_FRAME);
     }
+#undef P
+#undef sc
 }
 
 // ---- the render kernel: CR/RayTracer.cu:40-94 --------------------------------------------------
@@ -513,7 +545,8 @@ DEV void trace_stream(const RenderParams& P, const DevShade* shade, Counters& ct
 // path code dominates (at four it spills three times as much: c4_lucy 44 -> 57 ms/frame); four pays where shadow rays
 // walking meshes dominate, because that loop waits on dependent node loads (c5_final at 32 spp: 182 -> 169 ms/frame).
 template <bool STRICT, int SHADE_CAP, bool SHARE, int WAVES = RT_WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams P) {
+__global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams) {
+    RPREF P = KERNARG(RenderParams);
     const int lane = lane_id();
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
     __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
@@ -565,7 +598,8 @@ __global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams P) {
 // ---- pixel sums: CR/RayTracer.cu:74-89 ---------------------------------------------------------
 // One wave per 8x8 block, lane = slot.  The samples of a pixel are added in sample order, because the reference
 // adds them in that order inside one thread and double addition is not associative.
-__global__ __launch_bounds__(256) void resolve_kernel(RenderParams P) {
+__global__ __launch_bounds__(256) void resolve_kernel(RenderParams) {
+    RPREF P = KERNARG(RenderParams);
     const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t slot = threadIdx.x & 63u;
     if (blk >= P.n_blocks) return;
@@ -598,17 +632,16 @@ struct ProbeParams {
 __global__ __launch_bounds__(256) void probe_kernel(ProbeParams Q) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Q.w * Q.h) return;
-    RenderParams P;
-    P.sc = Q.sc, P.tex_w = Q.tex_w, P.tex_h = Q.tex_h, P.flags = Q.flags;
+    SCREF sc = KERNARG(ProbeParams).sc;
     int x, y;
-    map_pixel(P, Q.x0 + i % Q.w, Q.y0 + i / Q.w, x, y);
-    d3 d = emit(Q.sc, x, y);
+    map_pixel(Q.flags, Q.tex_w, Q.tex_h, sc.cam_w, sc.cam_h, Q.x0 + i % Q.w, Q.y0 + i / Q.w, x, y);
+    d3 d = emit(sc, x, y);
     if (Q.flags & RT_F_NORMALIZE_PRIMARY) d = unit(d);
     Counters ctr;
     uint32_t n = 0;
     uint32_t* log = Q.visit_log ? Q.visit_log + (size_t)i * Q.visit_cap : nullptr;
-    Hit h = log ? scene_closest<true, true>(Q.sc, Q.flags, Q.sc.camO, d, ctr, log, (uint32_t)Q.visit_cap, n, nullptr)
-                : scene_closest<true, false>(Q.sc, Q.flags, Q.sc.camO, d, ctr, nullptr, 0, n, nullptr);
+    Hit h = log ? scene_closest<true, true>(sc, Q.flags, Q.sc.camO, d, ctr, log, (uint32_t)Q.visit_cap, n, nullptr)
+                : scene_closest<true, false>(sc, Q.flags, Q.sc.camO, d, ctr, nullptr, 0, n, nullptr);
     Q.hit_prim[i] = h.prim;
     Q.hit_t[i] = h.dist;
     Q.hit_leaf[i] = h.leaf;

@@ -12,6 +12,7 @@
 // with a uniform index the compiler then fetches them with scalar loads into SGPRs, which keeps
 // the vector registers for per-lane ray state.
 #define RT_CONST __attribute__((address_space(4)))
+DEV d3 D3(const d3 RT_CONST& v) { return d3{v.x, v.y, v.z}; }  // a vector out of a record that is read in place
 
 // Intersection data of one top-level primitive (or of one cylinder segment of a Bezier stack),
 // with everything that does not depend on the ray computed once on the host: the same IEEE
@@ -93,6 +94,8 @@ struct DevScene {
     const rt_bvh_leaf* leaves;
     const uint8_t* texels;
 };
+// the scene record is read where it lies, in the kernel-argument segment (constant address space: scalar loads)
+#define SCREF const DevScene RT_CONST&
 #define GEOM(sc) ((const DevGeom RT_CONST*)(sc).geom)
 #define SEGS(sc) ((const DevGeom RT_CONST*)(sc).segs)
 #define LIGHTS(sc) ((const rt_light RT_CONST*)(sc).lights)
@@ -279,7 +282,7 @@ DEV double cylinder_hit(const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
 // CR/Collision_Bezier.cu:200-240: the profile as a stack of cylinders, including the way
 // `closest` trails one accepted hit behind.
 template <bool FULL>
-DEV double bezier_stacked_hit(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 V, double t_max, Hit& h) {
+DEV double bezier_stacked_hit(SCREF sc, const DevGeom RT_CONST& g, d3 o, d3 V, double t_max, Hit& h) {
     double closest = 1e10, cur = RT_BIG_DIST;
     for (int i = 0; i < g.aux1; i++) {
         const DevGeom RT_CONST& seg = SEGS(sc)[g.aux0 + i];
@@ -318,7 +321,7 @@ DEV void bz_horner(const DevGeom RT_CONST& co, int base, int n, double u, double
     val = v, der = dv;
 }
 template <bool FULL>
-DEV double bezier_newton_hit(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
+DEV double bezier_newton_hit(SCREF sc, const DevGeom RT_CONST& g, d3 o, d3 V, Hit& h) {
     const DevGeom RT_CONST& fr = SEGS(sc)[g.aux0 + g.aux1];
     const DevGeom RT_CONST& co = SEGS(sc)[g.aux0 + g.aux1 + 1];
     const int n = fr.aux1;
@@ -436,7 +439,7 @@ struct MeshResult {
 };
 
 template <bool STRICT, bool ANYHIT, bool LOG>
-DEV MeshResult mesh_walk(const DevScene& sc, uint32_t root, d3 o, d3 d, double t_limit, double cull_scale, Counters& ctr,
+DEV MeshResult mesh_walk(SCREF sc, uint32_t root, d3 o, d3 d, double t_limit, double cull_scale, Counters& ctr,
                          uint32_t* log, uint32_t log_cap, uint32_t& log_n, uint32_t log_tag) {
     MeshResult res{RT_BIG_DIST, RT_REF_END};
     const double t_exact = t_limit;  // ANYHIT: the caller's occlusion test is t_exact - t > 1e-6
@@ -512,7 +515,7 @@ DEV MeshResult mesh_walk(const DevScene& sc, uint32_t root, d3 o, d3 d, double t
 
 // Would the reference's depth-first walk (CR/Collision_Mesh.cu:65-80) have reached this leaf?  It does
 // iff the slab test of every ancestor passes; same arithmetic as mesh_walk<true, ...>.
-DEV bool reference_reaches_leaf(const DevScene& sc, uint32_t leaf_index, d3 o, d3 inv) {
+DEV bool reference_reaches_leaf(SCREF sc, uint32_t leaf_index, d3 o, d3 inv) {
     uint32_t n = sc.leaf_parent[leaf_index];
     while (n != RT_REF_END) {
         const rt_bvh_node& nd = sc.nodes[n];
@@ -551,7 +554,7 @@ DEV bool reference_reaches_leaf(const DevScene& sc, uint32_t leaf_index, d3 o, d
 #define RT_SIGN_SELECT(anyhit) (!(anyhit))
 #endif
 template <bool ANYHIT>
-DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk) {
+DEV MeshResult mesh_walk4(SCREF sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk) {
     const d3 inv = D3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     const double S = g.f[MSH_SCALE];
     const double mm = fmax(fmax((S + fabs(o.x)) * fabs(inv.x), (S + fabs(o.y)) * fabs(inv.y)), (S + fabs(o.z)) * fabs(inv.z));
@@ -714,7 +717,7 @@ DEV MeshResult mesh_walk4(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d
 static_assert(RT_SHARED_ROOTS >= 1 && (RT_SHARED_ROOTS - 1) + 3 * (RT_STACK / 3) <= RT_STACK, "roots + one tree walk fit the stack");
 // On entry the lane's stack (sp entries) holds the roots of the meshes its ray may enter; `S` = the largest mesh scale
 // of the scene (it only widens the error bounds).  The ray is passed by value and overwritten by hand-overs.
-DEV bool mesh_anyhit_shared(const DevScene& sc, double S, int sp, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk, uint32_t* xch) {
+DEV bool mesh_anyhit_shared(SCREF sc, double S, int sp, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const int lane = lane_id();
     uint32_t* flag = xch;
     uint32_t* x_lane = xch + 64;
@@ -847,7 +850,7 @@ DEV bool mesh_anyhit_shared(const DevScene& sc, double S, int sp, d3 o, d3 d, do
 // kept in LDS, and an accepted triangle is written to the ray's record by one lane at a time (distance, then pre-order
 // index: the rule of mesh_walk4), so the record ends up holding what a single lane would have found.
 // Must be called by all lanes that are active at the call site.  `xch` = 448 words of LDS of this wave.
-DEV MeshResult mesh_closest_shared(const DevScene& sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk,
+DEV MeshResult mesh_closest_shared(SCREF sc, const DevGeom RT_CONST& g, d3 o, d3 d, double t_limit, Counters& ctr, uint32_t* stk,
                                    uint32_t* xch) {
     const int lane = lane_id();
     uint32_t* x_lane = xch + 64;
@@ -1016,7 +1019,7 @@ DEV MeshResult mesh_closest_shared(const DevScene& sc, const DevGeom RT_CONST& g
 }
 
 // CR/Collision_Mesh.cu:45-60: hit record of the winning leaf (normal as CR/primitive.cpp:457 stores it)
-DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double t0, Hit& h) {
+DEV void mesh_fill_hit(SCREF sc, uint32_t leafref, d3 o, d3 d, double t0, Hit& h) {
     const rt_bvh_leaf& lf = sc.leaves[leafref & ~RT_REF_LEAF];
     d3 O1 = D3(lf.O1), e1 = D3(lf.O2) - O1, e2 = D3(lf.O3) - O1;
     h.C = o + d * t0;
@@ -1028,7 +1031,7 @@ DEV void mesh_fill_hit(const DevScene& sc, uint32_t leafref, d3 o, d3 d, double 
 
 // ---- closest hit over the scene: CR/Scene.cu:3-21, CR/Scene.cpp:27-38 ---------------------
 template <bool STRICT, bool LOG>
-DEV Hit scene_closest(const DevScene& sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint32_t* log, uint32_t log_cap,
+DEV Hit scene_closest(SCREF sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint32_t* log, uint32_t log_cap,
                       uint32_t& log_n, uint32_t* stk, uint32_t* xch = nullptr) {
     Hit best;
     best.prim = -1, best.leaf = -1, best.dist = RT_BIG_DIST, best.front = false;
@@ -1144,7 +1147,7 @@ DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2, double& s_out, double& t_ou
 #endif
 // `full` gets the primitives that, each on its own, hide the whole lamp from A (spheres and cylinders only: the
 // point lies in their umbra, every sample is occluded, none needs tracing).
-DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp, unsigned long long skip,
+DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp, unsigned long long skip,
                                         unsigned long long& full) {
     full = 0ull;
     if (sc.n_prims > 64) return ~0ull;
@@ -1281,7 +1284,7 @@ DEV unsigned long long light_candidates(const DevScene& sc, uint32_t flags, d3 A
 // ---- one shadow ray: CR/Shade.cu:36-46,64-75,94-105, CR/Light.cpp:35-40,67-78 ----------------
 // true = nothing between C and target.  A primitive occludes if dist - its_hit_distance > 1e-6.
 template <bool STRICT>
-DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
+DEV bool shadow_clear(SCREF sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
                       Counters& ctr, uint32_t* stk) {
     const d3 Vv = target - C;
     const double dist = module(Vv);
@@ -1345,7 +1348,7 @@ DEV bool shadow_clear(const DevScene& sc, uint32_t flags, d3 C, d3 target, int c
 
 // shadow_clear for the pruned mode, called by all 64 lanes (`act` = this lane has a ray): the meshes are walked with
 // mesh_anyhit_shared, so lanes without a ray, or whose ray is already known to be occluded, help the others.
-DEV bool shadow_clear_shared(const DevScene& sc, uint32_t flags, bool act, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
+DEV bool shadow_clear_shared(SCREF sc, uint32_t flags, bool act, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
                              Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const d3 Vv = target - C;
     const double dist = module(Vv);
@@ -1410,7 +1413,7 @@ DEV bool shadow_clear_shared(const DevScene& sc, uint32_t flags, bool act, d3 C,
 }
 
 // ---- textures: CR/bmp.cpp:133-150 (double taps), CR/Primitive.cu:85-115 (8-bit taps) --------
-DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevShade& px, double u, double v) {
+DEV d3 smooth_color(SCREF sc, uint32_t flags, const DevShade& px, double u, double v) {
     const int H = px.tex_h, W = px.tex_w;
     const bool u8 = (flags & RT_F_TEX_U8_TAPS) != 0;
     double U = (u - (u8 ? (double)floorf((float)u) : floor(u))) * H;
@@ -1460,7 +1463,7 @@ DEV d3 smooth_color(const DevScene& sc, uint32_t flags, const DevShade& px, doub
 
 // CR/Primitive.cu:16-83, CR/primitive.cpp:140-147,177-181,229-233
 DEV d3 T3(const DevShade& p, int i) { return d3{p.tf[i], p.tf[i + 1], p.tf[i + 2]}; }
-DEV d3 texture_color(const DevScene& sc, uint32_t flags, const DevShade& p, const Hit& c, Counters& ctr) {
+DEV d3 texture_color(SCREF sc, uint32_t flags, const DevShade& p, const Hit& c, Counters& ctr) {
     double u, v;
 #ifdef RT_ABLATE_UV  // timing experiments only: 1 = no sphere / cylinder mapping, 2 = no sphere, 3 = no cylinder
     if (RT_ABLATE_UV == 1 && p.type != RT_PRIM_PLANE) return D3(0.5, 0.5, 0.5);
