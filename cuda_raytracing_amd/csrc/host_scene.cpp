@@ -324,7 +324,9 @@ struct Builder {
         nodes[self].preorder = preorder++;
         int axis = (int)(depth % 3);
         const std::vector<V3>& c = centroid;
-        std::sort(ids.begin(), ids.end(), [axis, &c](uint32_t a, uint32_t b) { return c[a][axis] < c[b][axis]; });
+        // CR/primitive.cpp:566-569 sorts by the centroid alone, which leaves the order of equal centroids to the library's
+        // std::sort; the triangle index breaks such ties here, so the tree does not depend on the standard library
+        std::sort(ids.begin(), ids.end(), [axis, &c](uint32_t a, uint32_t b) { return c[a][axis] < c[b][axis] || (c[a][axis] == c[b][axis] && a < b); });
         size_t mid = ids.size() / 2;
         std::vector<uint32_t> l(ids.begin(), ids.begin() + mid), r(ids.begin() + mid, ids.end());
         Box bl, br;

@@ -1438,7 +1438,10 @@ DEV d3 smooth_color(SCREF sc, uint32_t flags, const DevShade& px, double u, doub
     __builtin_memcpy(&q22, base + ((size_t)U2 * W + V2) * 3, 4);
     const uint32_t t11[3] = {q11 & 255u, (q11 >> 8) & 255u, (q11 >> 16) & 255u}, t12[3] = {q12 & 255u, (q12 >> 8) & 255u, (q12 >> 16) & 255u};
     const uint32_t t21[3] = {q21 & 255u, (q21 >> 8) & 255u, (q21 >> 16) & 255u}, t22[3] = {q22 & 255u, (q22 >> 8) & 255u, (q22 >> 16) & 255u};
+    // CR/bmp.cpp:147-148 weights tap (U1,V2) by rat_U (1 - rat_V) and tap (U2,V1) by (1 - rat_U) rat_V; the .cu fetch indexes a
+    // transposed copy of the texture (CR/Renderer_CUDA.cpp:149-152), so in CR/Primitive.cu:109-110 the two taps swap weights
     double w1a = ru, w1b = rv, w2a = ru, w2b = 1 - rv, w3a = 1 - ru, w3b = rv, w4a = 1 - ru, w4b = 1 - rv;
+    if (u8) w2a = 1 - ru, w2b = rv, w3a = ru, w3b = 1 - rv;
     double out[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {

@@ -58,7 +58,10 @@ enum { RT_LIGHT_POINT = 0, RT_LIGHT_SQUARE = 1, RT_LIGHT_SPHERE = 2 };
 #define RT_F_TIE_LATER_WINS 0x004u    /* closest hit accepts temp-best < 1e-6 (CR/Scene.cu:14) vs temp < best (CR/Scene.cpp:33)        */
 #define RT_F_SHADOW_SELF_SKIP 0x008u  /* shadow tests skip the shaded primitive (CR/Shade.cu:38,67,97) vs test it (CR/Light.cpp:35,67)  */
 #define RT_F_SQUARE_UV_NO_ORIGIN 0x010u /* square UV from C.Dx (CR/Primitive.cu:46-47) vs (C-O).Dx (CR/primitive.cpp:230-231)           */
-#define RT_F_TEX_U8_TAPS 0x020u       /* each bilinear tap truncated to 8 bits before summing (helper_math.h:1842-1844) vs double taps (CR/bmp.cpp:146-149) */
+#define RT_F_TEX_U8_TAPS 0x020u       /* the .cu texture fetch (CR/Primitive.cu:85-115): floorf, each bilinear tap truncated to 8 bits before
+                                       * summing (helper_math.h:1842-1844), and taps (row U2, col V1) / (U1, V2) weighted rat_U (1 - rat_V) /
+                                       * (1 - rat_U) rat_V because the texture is uploaded transposed (CR/Renderer_CUDA.cpp:149-152,
+                                       * CR/Primitive.cu:109-110); vs double taps with the weights of CR/bmp.cpp:146-149 */
 #define RT_F_PIXEL_MAP_TRUNC 0x040u   /* pixel->camera map int((double)x/tex_w*cam_w) (CR/RayTracer.cu:55-56) vs exact floor(x*cam_w/tex_w) */
 #define RT_F_MESH_RAW_DIR 0x080u      /* mesh / triangle intersectors take the direction as given, so t is in units of |d| (CR/Collision_Mesh.cu:19-63, CR/Collision.cu:110-149; matters for shadow rays d = L-C and fuzzy reflections) vs normalised first like every other intersector */
 #define RT_F_BEZIER_STACKED 0x100u    /* Bezier = stack of cylinders incl. the `closest` bookkeeping of CR/Collision_Bezier.cu:200-240 vs Newton on the true surface of revolution */

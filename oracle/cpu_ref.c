@@ -499,7 +499,7 @@ static col_t scene_intersect(ctx_t* cx, v3 o, v3 d) {
     return best;
 }
 
-/* CR/bmp.cpp:133-150 (double taps) and CR/Primitive.cu:85-115 (8-bit truncated taps, floorf) */
+/* CR/bmp.cpp:133-150 (double taps) and CR/Primitive.cu:85-115 (8-bit truncated taps, floorf, weights of the transposed copy) */
 static v3 smooth_color(ctx_t* cx, const rt_texture* tx, double u, double v) {
     cx->st.texture_fetches++;
     int H = tx->height, W = tx->width;
@@ -522,7 +522,12 @@ static v3 smooth_color(ctx_t* cx, const rt_texture* tx, double u, double v) {
     const uint8_t* t12 = tx->rgb + ((size_t)U1 * W + V2) * 3;
     const uint8_t* t21 = tx->rgb + ((size_t)U2 * W + V1) * 3;
     const uint8_t* t22 = tx->rgb + ((size_t)U2 * W + V2) * 3;
+    /* Weights of the taps (U1,V2) and (U2,V1).  CR/bmp.cpp:147-148: ima[U1][V2] * rat_U * (1 - rat_V) and
+     * ima[U2][V1] * (1 - rat_U) * rat_V.  The .cu fetch reads a transposed copy (texture[col * H + row] = ima[row][col],
+     * CR/Renderer_CUDA.cpp:149-152), so CR/Primitive.cu:109 is ima[U2][V1] * rat_U * (1 - rat_V) and :110 is
+     * ima[U1][V2] * (1 - rat_U) * rat_V: the two taps carry each other's weights there. */
     double w1a = ru, w1b = rv, w2a = ru, w2b = 1 - rv, w3a = 1 - ru, w3b = rv, w4a = 1 - ru, w4b = 1 - rv;
+    if (u8) w2a = 1 - ru, w2b = rv, w3a = ru, w3b = 1 - rv;
     double out[3];
     for (int k = 0; k < 3; k++) {
         if (u8) {
@@ -542,6 +547,15 @@ static v3 smooth_color(ctx_t* cx, const rt_texture* tx, double u, double v) {
         }
     }
     return V3(out[0], out[1], out[2]);
+}
+
+/* test hook: one bilinear fetch in either tap mode */
+void orc_smooth_color(const rt_texture* tx, uint32_t flags, double u, double v, double out[3]) {
+    ctx_t cx;
+    memset(&cx, 0, sizeof cx);
+    cx.flags = flags;
+    v3 c = smooth_color(&cx, tx, u, v);
+    out[0] = c.x, out[1] = c.y, out[2] = c.z;
 }
 
 /* CR/Primitive.cu:16-83 and CR/primitive.cpp:140-147,177-181,229-233 */

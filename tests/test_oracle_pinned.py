@@ -160,3 +160,52 @@ def test_bezier_power_basis_equals_bernstein_form():
         for u in np.linspace(0, 1, 11):
             bern = sum(comb(n, i) * u ** i * (1 - u) ** (n - i) * P[i] for i in range(n + 1))
             assert abs(np.polyval(c[::-1], u) - bern) < 1e-9 * (1 + abs(bern)) * 4 ** n
+
+
+# ---- bilinear fetch: the CPU renderer's weights and the .cu files' weights, by hand ---------------------
+
+def _fetch(tex, flags, u, v):
+    tex = np.ascontiguousarray(tex, dtype=np.uint8)
+    t = abi.Texture(width=tex.shape[1], height=tex.shape[0], rgb=tex.ctypes.data_as(C.POINTER(C.c_uint8)))
+    out = (C.c_double * 3)()
+    orc.load().orc_smooth_color(C.byref(t), C.c_uint32(flags), C.c_double(u), C.c_double(v), out)
+    return list(out)
+
+
+def test_bilinear_taps_of_both_renderers_on_one_texel_quad():
+    """One fetch from an asymmetric 2x2 texture (rows = U, columns = V), expected values worked out by hand from the
+    reference's two fetch routines, not from the oracle.
+
+    u = 0.375, v = 0.125 on a 2x2 texture: U = 0.75, V = 0.25, U1 = V1 = 0, U2 = V2 = 1, rat_U = 0.25, rat_V = 0.75.
+    Channel 0 of the texels: ima[0][0] = 40, ima[0][1] = 80, ima[1][0] = 120, ima[1][1] = 200.
+
+    CR/bmp.cpp:146-149 (double taps; the / 256 of GetColor folded into the end):
+        ima[U1][V1] = ima[0][0] =  40 * .25 * .75 =  7.5
+        ima[U1][V2] = ima[0][1] =  80 * .25 * .25 =  5
+        ima[U2][V1] = ima[1][0] = 120 * .75 * .75 = 67.5
+        ima[U2][V2] = ima[1][1] = 200 * .75 * .25 = 37.5         -> 117.5 / 256
+
+    CR/Primitive.cu:108-111 on the transposed copy texture[col * H + row] = ima[row][col] (CR/Renderer_CUDA.cpp:149-152),
+    every product cut to 8 bits (helper_math.h:1842-1844):
+        texture[V1 * H + U1] = ima[0][0]: uchar(uchar( 40 * .25) * .75) = uchar( 10 * .75) =  7
+        texture[V1 * H + U2] = ima[1][0]: uchar(uchar(120 * .25) * .25) = uchar( 30 * .25) =  7
+        texture[V2 * H + U1] = ima[0][1]: uchar(uchar( 80 * .75) * .75) = uchar( 60 * .75) = 45
+        texture[V2 * H + U2] = ima[1][1]: uchar(uchar(200 * .75) * .25) = uchar(150 * .25) = 37   -> 96 / 256
+    (the CPU renderer's weights on 8-bit taps would give 7 + 5 + 67 + 37 = 116: the order of the weights matters.)"""
+    tex = np.zeros((2, 2, 3), dtype=np.uint8)
+    tex[0, 0] = (40, 41, 0)
+    tex[0, 1] = (80, 83, 255)
+    tex[1, 0] = (120, 127, 255)
+    tex[1, 1] = (200, 211, 0)
+    u, v = 0.375, 0.125
+    cpu = _fetch(tex, abi.RT_MODE_CPU_REF, u, v)
+    assert cpu[0] == 117.5 / 256
+    assert cpu[1] == (41 * .25 * .75 + 83 * .25 * .25 + 127 * .75 * .75 + 211 * .75 * .25) / 256
+    assert cpu[2] == (255 * .25 * .25 + 255 * .75 * .75) / 256
+    gpu = _fetch(tex, abi.RT_F_TEX_U8_TAPS, u, v)
+    assert gpu[0] == 96 / 256
+    # channel 1: uchar(uchar(10.25) * .75) = 7, uchar(uchar(31.75) * .25) = 7, uchar(uchar(62.25) * .75) = 46, uchar(uchar(158.25) * .25) = 39
+    assert gpu[1] == (7 + 7 + 46 + 39) / 256
+    # channel 2: 0, uchar(uchar(63.75) * .25) = 15, uchar(uchar(191.25) * .75) = 143, 0
+    assert gpu[2] == (15 + 143) / 256
+    assert gpu == _fetch(tex, abi.RT_MODE_GPU_REF, u, v)
