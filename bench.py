@@ -18,14 +18,19 @@ What the line reports
                            this is a rate of rays *resolved*;
   mrays_per_s_traced       the same with only the shadow rays that were actually intersected with the scene;
   mrays_per_s_primary_only pixels x samples per second, the one figure that can be derived for the reference's own timings;
-  roofline                 the render kernel against the roof that binds it: vector-ALU issue.  Its instruction mix is
-                           double-precision without fused multiply-add (bit parity with the reference forbids contraction),
-                           so the roof is one vector instruction per SIMD per 4 cycles; `achieved` = vector instructions of
-                           one launch (SQ_INSTS_VALU of the same command under rocprofv3, profiles/current/) x 64 lanes /
-                           the kernel time measured live with HIP events.  `flops_model` prices the same launch with the
-                           per-operation flop counts of the traversal (slab test 30, triangle test 60, ...) against the
-                           78.6 TFLOP/s FP64 vector peak; `hbm` puts the HBM counter traffic next to the bytes the kernel
-                           has to move (path colours + scene).
+  roofline                 the render kernel against the roof that binds it: vector-ALU issue.  `achieved` = vector
+                           instructions of one launch (SQ_INSTS_VALU of the same command under rocprofv3, profiles/current/)
+                           x 64 lanes / the kernel time measured live with HIP events; `peak` prices every instruction at
+                           4 cycles, so `frac` is issue-slot occupancy, not efficiency.  What is under it is printed beside
+                           it: `rate_weighted_issue_frac` (4 cycles for double precision, 2 for the rest), `lane_utilisation`
+                           (active lanes per vector instruction), `fp64_share`, `useful_frac` (double-precision operations
+                           of active lanes against the 78.6 TFLOP/s FMA peak).  The counters are used only if the file
+                           carries the build id of the library that is being timed (rt_build_id); otherwise `frac` is null
+                           and `counters_stale` true.  `flops_model` prices the launch with per-operation flop counts;
+                           `hbm` puts the HBM counter traffic next to the bytes the kernel has to move;
+                           `reference_order_pass` is the same frame traversed as the reference does, with the bytes of the
+                           64 / 72 / 48 / 128 / 16 / 4-byte model (node, triangle, ray, shaded hit, texture fetch, pixel)
+                           against the HBM peak; `survey_model` holds the same bytes against the pruned kernel's time.
   cpu_baseline             the CPU oracle (a port of the reference algorithm, OpenMP, every ray traced in reference order)
                            on a bounded sample of the same frame; for c1 also the reference's own CPU renderer.
 """
@@ -119,15 +124,27 @@ def cpu_baseline(hs, st, width, height, budget_s=25.0):
                       f"({rays} rays in {dt:.1f} s; every ray traced, reference-order traversal, OpenMP over rows)"}
 
 
-def profile_counters(config):
+def profile_counters(config, build_id):
     """Counters of one render-kernel launch of this configuration (one frame), from the rocprofv3 PMC passes of the same
-    command that tools/profile_round.sh summarised under profiles/current/ (rocprofv3 cannot run inside this process)."""
+    command that tools/profile_round.sh summarised under profiles/current/ (rocprofv3 cannot run inside this process).
+    Returns (counters, path, stale): counters collected with another build of the library are not returned."""
     path = os.path.join(ROOT, "profiles", "current", f"pmc_{config}.json")
     try:
         with open(path) as f:
-            return json.load(f), os.path.relpath(path, ROOT)
+            pmc = json.load(f)
     except Exception:
-        return None, None
+        return None, None, False
+    if pmc.get("build_id") != build_id:
+        return None, os.path.relpath(path, ROOT), True
+    return pmc, os.path.relpath(path, ROOT), False
+
+
+def algorithmic_bytes(s):
+    """Bytes the reference's own traversal of the frame touches: 64 per node visited, 72 per triangle tested, 48 per ray (origin
+    and direction), 128 per shaded hit (primitive / material record), 16 per texture fetch, 4 per pixel written.  The counts
+    must come from a reference-order render (every ray traced, no culling)."""
+    return (64.0 * s.nodes_visited + 72.0 * s.tris_tested + 48.0 * s.rays + 128.0 * s.shaded_hits + 16.0 * s.texture_fetches
+            + 4.0 * s.pixels)
 
 
 def reference_c1():
@@ -202,9 +219,23 @@ def main():
     gather = FrameGather(W, H, args.tile, rank, world, torch.device(comm))
     frame = [None]
 
+    exchange_ms = [0.0]
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
     def step():
         _, s = ds.render_frame(st, W, H, tile=args.tile, part=rank, n_parts=world, out=image)
-        frame[0] = gather.gather(image.cpu() if rehearse else image)
+        if world == 1:
+            frame[0] = image
+        elif rehearse:
+            t = time.perf_counter()
+            frame[0] = gather.gather(image.cpu())
+            exchange_ms[0] += (time.perf_counter() - t) * 1e3
+        else:  # pack kernel, gather over RCCL, unpack kernel: all on this stream (rank 0 also waits here for the slowest peer's pack)
+            ev[0].record(stream)
+            frame[0] = gather.gather(image)
+            ev[1].record(stream)
+            ev[1].synchronize()
+            exchange_ms[0] += ev[0].elapsed_time(ev[1])
         return s
 
     def sync():
@@ -223,6 +254,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    exchange_ms[0] = 0.0
     t0 = time.perf_counter()
     kernel_ms = 0.0
     last = None
@@ -238,13 +270,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     frame_rays, frame_primary, frame_traced = (float(x) for x in rays.tolist())
+    # every rank's own kernel time and time in the exchange, so that a multi-GPU line explains its own efficiency
+    per_rank = torch.zeros((world, 2), dtype=torch.float64, device=comm)
+    per_rank[rank, 0] = kernel_ms / args.steps
+    per_rank[rank, 1] = exchange_ms[0] / args.steps
+    if world > 1:
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    per_rank = per_rank.tolist()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         dof_txt = f"depth of field on (aperture {aperture:g}, focal {focal:g})" if dof else "depth of field off"
         mesh_txt = "Lucy 34k-tri " if scene_name == "c4_lucy" else ""
         out = {
-            "metric": f"Mrays/s (primary + reflect/refract + shadow rays the reference traces for the frame), {mesh_txt}{scene_name} {W}x{H} {spp}spp",
+            "metric": f"Mrays/s (primary + reflect/refract + shadow rays the reference traces for the frame, over the frame time; seconds_per_frame beside it), {mesh_txt}{scene_name} {W}x{H} {spp}spp",
             "value": frame_rays * args.steps / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -272,18 +311,31 @@ def main():
         kname = "render_kernel<false, %d, %s%s>" % (cap, "true" if picked == 1 else "false", ", 4" if ds.waves_per_simd == 4 else "")
         out["config"]["shadow_walk_variant"] = {0: "plain", 1: "shared"}[picked]
         kavg = kernel_ms / args.steps
-        pmc, pmc_path = profile_counters(args.config)
+        build_id = abi.load_library().rt_build_id().decode()
+        pmc, pmc_path, stale = profile_counters(args.config, build_id)
         counters = {"rays_traced": last.rays_traced, "nodes_visited": last.nodes_visited, "tris_tested": last.tris_tested, "shaded_hits": last.shaded_hits,
                     "texture_fetches": last.texture_fetches, "n_prims": n_prims, "n_lights": hs.desc.n_lights}
         flops = flops_model(counters)
         needed = 24.0 * last.rays_primary * 2 + 4.0 * last.pixels + 7.0e6  # path colours written, then read by the resolve kernel; the frame; the scene once
         roof = {"bound": "valu_issue", "unit": "T lane-instr/s", "peak": VALU_LANE_OPS_PEAK, "achieved": None, "frac": None, "traffic": None,
-                "kernel": kname, "kernel_ms_avg": kavg, "launches_per_frame": 1,
-                "peak_note": f"{SIMDS} SIMDs x 16 lanes x {CLOCK_GHZ} GHz: one 64-lane vector instruction per SIMD per 4 cycles (FP64 at full rate; "
+                "kernel": kname, "kernel_ms_avg": kavg, "launches_per_frame": 1, "library_build_id": build_id,
+                "frac_is": "issue-slot occupancy (every vector instruction priced at 4 cycles, all 64 lanes counted): see rate_weighted_issue_frac, "
+                           "lane_utilisation and useful_frac for what is under it",
+                "peak_note": f"{SIMDS} SIMDs x 16 lanes x {CLOCK_GHZ} GHz: one 64-lane vector instruction per SIMD per 4 cycles (the FP64 rate; "
                              f"no FMA contraction, so the {FP64_VECTOR_TFLOPS} TFLOP/s FMA figure is out of reach by construction)",
                 "flops_model": {"flops_per_launch": flops, "achieved_tflops": flops / (kavg * 1e-3) / 1e12, "peak_tflops": FP64_VECTOR_TFLOPS,
                                 "frac": flops / (kavg * 1e-3) / 1e12 / FP64_VECTOR_TFLOPS},
                 "hbm": {"bytes_needed_per_launch": needed, "peak_gbps": HBM_PEAK_GBPS}}
+        if stale:
+            roof["counters_stale"] = True
+            roof["counters_from"] = pmc_path
+            roof["counters_note"] = "the counter file was collected with another build of the library: run tools/profile_round.sh with this one"
+        if world > 1:
+            roof["kernel_ms_per_rank"] = {"min": min(r[0] for r in per_rank), "max": max(r[0] for r in per_rank), "all": [r[0] for r in per_rank]}
+            roof["exchange_ms"] = per_rank[0][1]
+            roof["exchange_ms_per_rank"] = [r[1] for r in per_rank]
+            roof["exchange_note"] = ("pack kernel + gather + unpack kernel per frame, timed on each rank's stream" if not rehearse else
+                                     "rehearsal: host copies over gloo, wall clock") + "; rank 0's figure includes waiting for the slowest peer"
         if world == 1 and pmc:
             try:
                 sq = pmc["pmc_sq"]
@@ -297,6 +349,24 @@ def main():
             except Exception:
                 pass
             try:
+                a, b = pmc["pmc_mix_a"], pmc["pmc_mix_b"]
+                n_valu = a["SQ_INSTS_VALU"]
+                n_f64 = a["SQ_INSTS_VALU_ADD_F64"] + a["SQ_INSTS_VALU_MUL_F64"] + a["SQ_INSTS_VALU_FMA_F64"] + a["SQ_INSTS_VALU_TRANS_F64"]
+                lane_util = b["SQ_THREAD_CYCLES_VALU"] / (64.0 * b["SQ_ACTIVE_INST_VALU"])
+                f64_ops = (n_f64 + a["SQ_INSTS_VALU_FMA_F64"]) * 64.0 * lane_util  # an FMA is two operations; lanes as active as the average instruction's
+                simd_cycles = SIMDS * CLOCK_GHZ * 1e9 * (kavg * 1e-3)
+                roof["lane_utilisation"] = lane_util
+                roof["fp64_share"] = n_f64 / n_valu
+                roof["useful_tflops"] = f64_ops / (kavg * 1e-3) / 1e12
+                roof["useful_frac"] = roof["useful_tflops"] / FP64_VECTOR_TFLOPS
+                roof["rate_weighted_issue_frac"] = (4.0 * n_f64 + 2.0 * (n_valu - n_f64)) / simd_cycles
+                roof["instruction_mix"] = {"fp64": n_f64 / n_valu,
+                                           "fp32": (b["SQ_INSTS_VALU_ADD_F32"] + b["SQ_INSTS_VALU_MUL_F32"] + b["SQ_INSTS_VALU_FMA_F32"] + b["SQ_INSTS_VALU_TRANS_F32"]) / n_valu,
+                                           "int_and_convert": (a["SQ_INSTS_VALU_INT32"] + a["SQ_INSTS_VALU_INT64"] + a["SQ_INSTS_VALU_CVT"]) / n_valu}
+                roof["instruction_mix"]["moves_selects_compares_exchanges"] = 1.0 - sum(roof["instruction_mix"].values())
+            except Exception:
+                pass
+            try:
                 traffic = (pmc["pmc_fetch"]["FETCH_SIZE"] + pmc["pmc_write"]["WRITE_SIZE"]) * 1024.0
                 roof["traffic"] = traffic
                 roof["hbm"].update({"traffic_bytes_per_launch": traffic, "achieved_gbps": traffic / (kavg * 1e-3) / 1e9,
@@ -306,9 +376,18 @@ def main():
             except Exception:
                 pass
         if strict_stats is not None:
+            ab = algorithmic_bytes(strict_stats)
+            gbps = ab / (strict_stats.kernel_ms * 1e-3) / 1e9
             roof["reference_order_pass"] = {"kernel_ms": strict_stats.kernel_ms, "nodes_visited": strict_stats.nodes_visited,
-                                            "tris_tested": strict_stats.tris_tested,
-                                            "note": "the same frame with the reference's own traversal (every ray traced, no culling): what the pruned kernel avoids"}
+                                            "tris_tested": strict_stats.tris_tested, "rays": strict_stats.rays,
+                                            "algorithmic_bytes": ab, "algorithmic_gbps": gbps, "frac_of_hbm": gbps / HBM_PEAK_GBPS,
+                                            "note": "the same frame with the reference's own traversal (every ray traced, no culling): the kernel that does the "
+                                                    "work the byte model prices (64 B per node visit, 72 per triangle test, 48 per ray, 128 per shaded hit, 16 per "
+                                                    "texture fetch, 4 per pixel); the tree stays in L2 / Infinity Cache, so these bytes are cache traffic, not HBM"}
+            roof["survey_model"] = {"algorithmic_bytes": ab, "gbps_at_pruned_kernel_time": ab / (kavg * 1e-3) / 1e9,
+                                    "frac_of_hbm": ab / (kavg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    "note": "above 1: the pruned kernel does not do this work (it walks its own four-wide tree and decides most shadow "
+                                            "samples without a ray; same image bit for bit), so the byte model cannot grade it"}
         out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hs, st, W, H, budget_s=25.0 if args.config != "c1" else 5.0)

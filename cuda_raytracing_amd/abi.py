@@ -168,7 +168,6 @@ _SIGNATURES = {
     "rt_scene_check_trees": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "rt_scene_shared_walk": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rt_scene_waves_per_simd": (C.c_int, [C.c_void_p]),
-    "rt_scene_deferred_shadows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "rt_scene_create": (C.c_int, [_P(SceneDesc), _P(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
     "rt_render_tile": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p, _P(Stats)]),
@@ -186,8 +185,13 @@ _SIGNATURES = {
     "rt_unpack_tiles_all": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "rt_trace_primary": (C.c_int, [C.c_void_p, _P(Settings)] + [C.c_int] * 8 + [C.c_void_p] * 5 + [C.c_int]),
     "rt_last_error": (C.c_char_p, []),
+    "rt_build_id": (C.c_char_p, []),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+# only in libraries built with -DRT_EXPERIMENTS (A/B timing builds): bound when present
+_OPTIONAL_SIGNATURES = {
+    "rt_scene_deferred_shadows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+}
 
 _lib = None
 
@@ -205,9 +209,19 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _OPTIONAL_SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     if path is None:
         _lib = lib
     return lib
+
+
+def has_experiments(lib=None):
+    """True if the loaded library was built with -DRT_EXPERIMENTS (it then carries the three-kernel render)."""
+    return hasattr(lib or load_library(), "rt_scene_deferred_shadows")
 
 
 class RtError(RuntimeError):

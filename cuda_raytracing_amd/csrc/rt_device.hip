@@ -144,9 +144,7 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
         const DevShade& m = shade[h.prim];
         color = D3(m.color);
         m_diff = m.diff, m_spec = m.spec;
-#ifndef RT_ABLATE_TEXTURE  // timing experiments only
         if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, m, h, ctr));
-#endif
         ctr.shaded++;
     }
     RT_LAP(ctr, PF_SHADE_SETUP);
@@ -220,20 +218,14 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
                     else k0 = true;
                 }
                 ctr.u[6] += k0, ctr.u[8] += k1, ctr.u[10] += k2;
-#ifndef RT_PAIR_STATS
                 ctr.u[7] += (k0 && !k1 && !k2), ctr.u[9] += (k1 && !k0 && !k2), ctr.u[11] += (k2 && !k0 && !k1);
-#endif
             }
 #endif
             RT_LAP(ctr, PF_CHUNK_SHFL);
             RT_FRESH();
             d3 target = d3{L.O.x, L.O.y, L.O.z};
             if (act) {
-#ifdef RT_ABLATE_RNG
-                if (false) {
-#else
                 if (!point) {
-#endif
                     float fa, fb;
                     frand_pair(P.k0, P.k1, opix, osmp, odraw + off + 2u * (uint32_t)si, fa, fb);
                     target = light_sample(L, fa, fb);
@@ -258,9 +250,6 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
             }
         }
         RT_LAP(ctr, PF_CHUNK_SHFL);
-#ifdef RT_PAIR_STATS
-        if (heavy) { ctr.u[7] += 1; ctr.u[9] += (cnt == n_l) ? 1u : 0u; ctr.u[11] += (cnt == 0) ? 1u : 0u; }
-#endif
         RT_FRESH();
         if (need && dt > RT_EPS) {
             double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
@@ -417,9 +406,6 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
         if (surface) {
             const DevShade& m = shade[h.prim];
             need_shade = m.diff > RT_EPS || m.spec > RT_EPS;
-#ifdef RT_ABLATE_SHADING  // timing experiments only: paths without any local shading (same rays, wrong colours)
-            need_shade = false;
-#endif
         }
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);
@@ -433,11 +419,7 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
                 const DevShade& m = shade[h.prim];
                 d3 acc = D3(0, 0, 0);
                 if (need_shade) acc = acc + local;
-#ifdef RT_ABLATE_SECONDARY  // timing experiments only: primary rays and their shading, nothing after them
-                const bool has_refl = false, has_refr = false;
-#else
                 const bool has_refl = m.refl > RT_EPS, has_refr = m.refr > RT_EPS;
-#endif
                 if (has_refl || has_refr) {
                     const int k = sp;
                     f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
@@ -614,7 +596,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(RenderParams) {
     *reinterpret_cast<uint32_t*>(P.out + ((size_t)py * (size_t)P.tex_w + (size_t)px) * 4) = rgba;
 }
 
-#include "rt_defer.hpp"
+#ifdef RT_EXPERIMENTS
+#include "rt_defer.hpp"  // the same render as three lean kernels: measured slower everywhere, kept for A/B runs only
+#endif
 
 // ---- debug kernel: primary ray of every pixel, reference-order walk with a visit log ------------
 struct ProbeParams {
@@ -666,12 +650,14 @@ struct Workspace {
     double* path_out = nullptr;              // colours of the finished paths of one launch
     size_t path_out_bytes = 0;
     bool fixed = false;                      // true: the buffers above are all there is (nothing may be allocated or grown)
+#ifdef RT_EXPERIMENTS
     // the three-kernel render (rt_defer.hpp): node records, shadow jobs per lamp, allocation counters, last node per path
     NodeRec* nodes = nullptr;
     JobRec* jobs = nullptr;
     uint32_t* alloc = nullptr;
     uint32_t* last_node = nullptr;
     size_t nodes_cap = 0, jobs_cap = 0, last_cap = 0;
+#endif
 };
 
 struct rt_scene {
@@ -684,9 +670,11 @@ struct rt_scene {
     size_t image_bytes = 0;
     int shared_walk = 0;                   // shadow mesh walks shared by the wave (render_kernel<.., SHARE = true>): 0 = no, 1 = yes
     int waves = RT_WAVES_PER_SIMD;         // kernel build the scene gets: RT_WAVES_PER_SIMD, or 4 for mesh-heavy scenes (shared variant only)
+#ifdef RT_EXPERIMENTS
     int defer = 0;                         // pruned renders go through the three-kernel path (rt_defer.hpp) instead of the one kernel
     uint32_t launch_id = 0;                // tag of the last launch of the three-kernel render
     int defer_fallbacks = 0;               // calls that had to be rendered again by the one kernel because a record buffer was too small
+#endif
     size_t n_blocks = 0;                   // blocks in ws.blocks: those of last_tiles
     std::vector<Tile> last_tiles;
     int cus = 0, blocks_per_cu_fast = 0, blocks_per_cu_strict = 0;
@@ -713,6 +701,7 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
 #define RT_MAX_DEVICES 64
 static std::mutex g_scratch_mutex;
 static unsigned char* g_scratch_ptr[RT_MAX_DEVICES];  // per device: where that GPU's copy of `scratch` lives (null = not looked up yet)
+static std::mutex g_scratch_use[RT_MAX_DEVICES];      // per device: held by the one call that is working in that GPU's copy
 
 // Address of the current device's copy of `scratch`.  The array's name is only a handle on the host; every use of the
 // array's memory from host code (kernel arguments, memsets, copies) goes through the pointer returned here.
@@ -813,10 +802,12 @@ extern "C" void rt_scene_destroy(rt_scene* s) {
     if (s->ws.queue) (void)hipFree(s->ws.queue);
     if (s->ws.counters) (void)hipFree(s->ws.counters);
     if (s->image) (void)hipFree(s->image);
+#ifdef RT_EXPERIMENTS
     if (s->ws.nodes) (void)hipFree(s->ws.nodes);
     if (s->ws.jobs) (void)hipFree(s->ws.jobs);
     if (s->ws.alloc) (void)hipFree(s->ws.alloc);
     if (s->ws.last_node) (void)hipFree(s->ws.last_node);
+#endif
     if (s->ws.path_out) (void)hipFree(s->ws.path_out);
     if (s->ws.blocks) (void)hipFree(s->ws.blocks);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -939,6 +930,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->shared_walk = (v.mesh_scale_max > 0.0 && v.n_prims <= RT_SHADE_LDS) ? 1 : 0;
     if (const char* e = std::getenv("RT_AMD_SHARED_WALK"))
         if ((e[0] == '0' || e[0] == '1') && v.n_prims <= RT_SHADE_LDS) s->shared_walk = e[0] - '0';
+#ifdef RT_EXPERIMENTS
     // The three-kernel render needs room for every lamp in a node record and the primitive index in 24 bits.
     {
         const bool can = d->n_lights <= RT_DEFER_LAMPS && d->n_primitives < (1 << 24) && v.shade_n < (1 << 16);
@@ -946,6 +938,7 @@ extern "C" int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         if (const char* e = std::getenv("RT_AMD_DEFER"))
             if (e[0] == '1' && can) s->defer = 1;
     }
+#endif
     // Four waves per SIMD where shadow walks over meshes carry the frame: several meshes, or one large one (more triangles than
     // 64 Ki).  RT_AMD_WAVES=3|4 overrides the rule.
     {
@@ -1010,7 +1003,7 @@ static int blocks_of(const std::vector<Tile>& tiles, std::vector<BlockRec>& recs
 }
 
 // Render the given tiles into `dst` (device image).  Fills kernel time and counters.
-#ifndef RT_DEFER_PATHS
+#if defined(RT_EXPERIMENTS) && !defined(RT_DEFER_PATHS)
 #define RT_DEFER_PATHS (1ull << 25)  // most paths of one launch of the three-kernel render (node records + jobs: about 0.9 KB per path)
 #endif
 static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h,
@@ -1027,6 +1020,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         if (rc) return rc;
         if (recs.size() > ws.blocks_cap) {
             if (ws.fixed) return rt_fail(RT_ERR_LIMIT, "rectangle has more 8x8 pixel blocks than the fixed workspace holds");
+            s->last_tiles.clear(), s->n_blocks = 0;  // the cached list goes with its buffer (a failed allocation below must not leave a cache hit)
             if (ws.blocks) (void)hipFree(ws.blocks);
             ws.blocks = nullptr, ws.blocks_cap = 0;
             const size_t cap = recs.size() + 1024;
@@ -1049,8 +1043,12 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         const unsigned long long v = std::strtoull(e, nullptr, 10);
         if (v >= 64 && v < launch_paths) launch_paths = v;
     }
+#ifdef RT_EXPERIMENTS
     const bool defer = allow_defer && !strict && !ws.fixed && s->defer == 1;
     if (defer) launch_paths = std::min<uint64_t>(launch_paths, RT_DEFER_PATHS);
+#else
+    (void)allow_defer;
+#endif
     if (ws.fixed) {
         const uint64_t cap = ws.path_out_bytes / (3 * sizeof(double));
         if (cap < block_paths) return rt_fail(RT_ERR_LIMIT, "too many samples per pixel for the fixed workspace (one 8x8 block must fit)");
@@ -1066,6 +1064,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         ws.path_out_bytes = out_bytes;
     }
     HIPCHK(hipMemsetAsync(ws.counters, 0, sizeof(unsigned long long) * (CTR_ALL + 16), g_stream));
+#ifdef RT_EXPERIMENTS
     DeferParams D{};
     if (defer) {
         // record buffers for the largest launch of this call: six nodes per path (a path has one node per ray it traces), and per
@@ -1105,6 +1104,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         D.nodes_cap = (uint32_t)std::min<size_t>(std::min(ws.nodes_cap, want_nodes), 0xFFFFFFF0u), D.jobs_cap = (uint32_t)ws.jobs_cap;
         D.overflow = ws.counters + (CTR_ALL + 15);
     }
+#endif
 
     RenderParams P;
     P.sc = s->dev;
@@ -1126,6 +1126,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         uint64_t grid = (uint64_t)s->cus * bpc;
         const uint64_t want_blocks = ((uint64_t)P.n_paths + 255) / 256;
         if (grid > want_blocks) grid = want_blocks;
+#ifdef RT_EXPERIMENTS
         if (defer) {
             // path kernel (no shadow rays) -> shadow kernel (every job) -> fold kernel (colours), see rt_defer.hpp
             HIPCHK(hipMemsetAsync(ws.alloc, 0, 256, g_stream));
@@ -1149,6 +1150,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
             HIPCHK(hipGetLastError());
             return RT_OK;
         }
+#endif
         const dim3 g((unsigned)grid), t(256);
         if (strict) hipLaunchKernelGGL((render_kernel<true, 0, false>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= 16 && four) hipLaunchKernelGGL((render_kernel<false, 16, true, 4>), g, t, 0, g_stream, P);
@@ -1171,10 +1173,12 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
     unsigned long long c[CTR_ALL + 16];
     HIPCHK(hipMemcpyAsync(c, ws.counters, sizeof(c), hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+#ifdef RT_EXPERIMENTS
     if (defer && c[CTR_ALL + 15] != 0ull) {  // a record buffer was too small for this call: the one kernel renders it
         s->defer_fallbacks++;
         return launch_tiles(s, ws, st, tex_w, tex_h, cam_w, cam_h, tiles, dst, stats, false);
     }
+#endif
 #ifdef RT_UTIL_COUNTERS
     std::fprintf(stderr, "[util] shadow lanes used %.1f%% (%llu of %llu slots), closest-hit lanes used %.1f%% (%llu of %llu slots)\n",
                  100.0 * c[CTR_U_SHADOW_ITEMS] / (double)(c[CTR_U_SHADOW_SLOTS] ? c[CTR_U_SHADOW_SLOTS] : 1), c[CTR_U_SHADOW_ITEMS], c[CTR_U_SHADOW_SLOTS],
@@ -1261,8 +1265,10 @@ extern "C" int rt_render_tile(rt_scene* s, const rt_settings* st, int tex_w, int
 // rt_render_tile for callers that may not allocate device memory: the same kernels, with the queue heads, counters, block
 // list and path colours in this GPU's copy of `scratch` instead of buffers the scene owns and grows.  Nothing here calls
 // hipMalloc / hipFree.  The array keeps the previous call's contents: the queue heads and counters are cleared per launch,
-// the block list is rewritten, and path colours are read only where this call wrote them.  Calls that overlap on one GPU
-// (other threads, other streams, other scenes) would share the array and race.
+// the block list is rewritten, and path colours are read only where this call wrote them.  Calls of this process that overlap on
+// one GPU (other threads, other scenes) take turns: a per-device mutex is held from the first write to the array until the
+// call's last kernel has finished.  Not for a capturing stream: the call copies the block list in, reads the counters back and
+// synchronises the stream.
 extern "C" int rt_render_tile_noalloc(rt_scene* s, const rt_settings* st, int tex_w, int tex_h, int cam_w, int cam_h, int x0, int y0, int w,
                                       int h, uint8_t* rgba_device, rt_stats* stats) {
     auto t0 = std::chrono::steady_clock::now();
@@ -1289,7 +1295,10 @@ extern "C" int rt_render_tile_noalloc(rt_scene* s, const rt_settings* st, int te
     ws.blocks = reinterpret_cast<BlockRec*>(base + RT_NOALLOC_OFF_BLOCKS), ws.blocks_cap = RT_NOALLOC_BLOCKS;
     ws.path_out = reinterpret_cast<double*>(base + RT_NOALLOC_OFF_PATHS), ws.path_out_bytes = (size_t)RT_NOALLOC_PATHS * 24u;
     std::vector<Tile> tiles{Tile{x0, y0, w, h}};
-    rc = launch_tiles(s, ws, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba_device, stats);
+    {
+        std::lock_guard<std::mutex> turn(g_scratch_use[s->device]);  // launch_tiles returns after the stream has been synchronised
+        rc = launch_tiles(s, ws, st, tex_w, tex_h, cam_w, cam_h, tiles, rgba_device, stats);
+    }
     if (rc) return rc;
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RT_OK;

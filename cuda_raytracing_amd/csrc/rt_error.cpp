@@ -12,3 +12,10 @@ int rt_fail(int code, const std::string& msg) {
 }
 
 extern "C" const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+// Identity of this build: a hash of the library's sources and compiler flags, passed in by the build script.  Measurements
+// taken with one build (profiler counters kept in files) can then be told apart from a library built from other sources.
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unidentified"
+#endif
+extern "C" const char* rt_build_id(void) { return RT_BUILD_ID; }

@@ -8,6 +8,13 @@
 #define RT_TRACE_HPP
 #include "rt_math.hpp"
 
+// -DRT_EXPERIMENTS puts the measurement scaffolding into the library: the render as three lean kernels (rt_defer.hpp) and, with
+// -DRT_UTIL_COUNTERS on top of it, section timers and lane-use probes inside the render kernel.  tools/ab.sh builds such
+// libraries for timing runs; the shipped library has neither.
+#if defined(RT_UTIL_COUNTERS) && !defined(RT_EXPERIMENTS)
+#error "RT_UTIL_COUNTERS instruments the render kernel: build it with -DRT_EXPERIMENTS as well (tools/ab.sh)"
+#endif
+
 // Wave-uniform tables (primitive geometry, lights) are read through the constant address space:
 // with a uniform index the compiler then fetches them with scalar loads into SGPRs, which keeps
 // the vector registers for per-lane ray state.
@@ -1046,14 +1053,6 @@ DEV Hit scene_closest(SCREF sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint3
         double t = RT_BIG_DIST;
         // a hit can only replace the best one if it is closer (or within 1e-6 under later-wins)
         const double lim = later_wins ? best.dist + RT_EPS : best.dist;
-#ifdef RT_ABLATE_CLOSEST_PRIMS  // timing experiments only: 1 = meshes and planes only, 2 = no spheres
-        if (RT_ABLATE_CLOSEST_PRIMS == 1 && g.type != RT_PRIM_MESH && g.type != RT_PRIM_PLANE) continue;
-        if (RT_ABLATE_CLOSEST_PRIMS == 2 && g.type == RT_PRIM_SPHERE) continue;
-        if (RT_ABLATE_CLOSEST_PRIMS == 3 && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER)) continue;
-        if (RT_ABLATE_CLOSEST_PRIMS == 4 && sc.n_prims > 0 && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER)) continue;  // code kept, work skipped
-        if (RT_ABLATE_CLOSEST_PRIMS == 5 && sc.n_prims > 0 && g.type == RT_PRIM_BEZIER) continue;
-        if (RT_ABLATE_CLOSEST_PRIMS == 6 && sc.n_prims > 0 && g.type == RT_PRIM_CYLINDER) continue;
-#endif
         switch (g.type) {
             case RT_PRIM_SPHERE: t = sphere_hit<true>(g, o, V, tmp); break;
             case RT_PRIM_PLANE: t = plane_hit<true>(g, o, V, tmp); break;
@@ -1084,9 +1083,6 @@ DEV Hit scene_closest(SCREF sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint3
             }
             default: break;
         }
-#ifdef RT_ABLATE_CLOSEST_PRIMS
-        if (RT_ABLATE_CLOSEST_PRIMS == 7 && g.type == RT_PRIM_CYLINDER && t != -1.0) t = RT_BIG_DIST;  // test paid for, hit thrown away
-#endif
         if (t < RT_BIG_DIST) {
             bool take = later_wins ? (t - best.dist < RT_EPS) : (t < best.dist);
             if (take) {
@@ -1292,9 +1288,6 @@ DEV bool shadow_clear(SCREF sc, uint32_t flags, d3 C, d3 target, int crashed, in
     const d3 dm = (flags & RT_F_MESH_RAW_DIR) ? Vv : V;
     uint32_t dummy_n = 0;
     const bool self_skip = (flags & RT_F_SHADOW_SELF_SKIP) != 0;
-#ifdef RT_ABLATE_ALL_SHADOW  // timing experiments only: results are wrong in RT_ABLATE_* builds
-    return dist > 0;
-#endif
     for (int j = 0; j < sc.n_prims; j++) {
         if (!STRICT) {
             // primitives that cannot lie between any lane's shaded point and its lamp are skipped by the whole wave
@@ -1307,15 +1300,6 @@ DEV bool shadow_clear(SCREF sc, uint32_t flags, d3 C, d3 target, int crashed, in
         const DevGeom RT_CONST& g = GEOM(sc)[j];
         Hit tmp;
         double t = RT_BIG_DIST;
-#ifdef RT_ABLATE_MESH
-        if (g.type == RT_PRIM_MESH) continue;
-#endif
-#ifdef RT_ABLATE_CYL
-        if (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER) continue;
-#endif
-#ifdef RT_ABLATE_SPHERE
-        if (g.type == RT_PRIM_SPHERE || g.type == RT_PRIM_PLANE) continue;
-#endif
         switch (g.type) {
             case RT_PRIM_SPHERE: t = sphere_hit<false>(g, C, V, tmp); break;
             case RT_PRIM_PLANE: t = plane_hit<false>(g, C, V, tmp); break;
@@ -1468,11 +1452,6 @@ DEV d3 smooth_color(SCREF sc, uint32_t flags, const DevShade& px, double u, doub
 DEV d3 T3(const DevShade& p, int i) { return d3{p.tf[i], p.tf[i + 1], p.tf[i + 2]}; }
 DEV d3 texture_color(SCREF sc, uint32_t flags, const DevShade& p, const Hit& c, Counters& ctr) {
     double u, v;
-#ifdef RT_ABLATE_UV  // timing experiments only: 1 = no sphere / cylinder mapping, 2 = no sphere, 3 = no cylinder
-    if (RT_ABLATE_UV == 1 && p.type != RT_PRIM_PLANE) return D3(0.5, 0.5, 0.5);
-    if (RT_ABLATE_UV == 2 && p.type == RT_PRIM_SPHERE) return D3(0.5, 0.5, 0.5);
-    if (RT_ABLATE_UV == 3 && p.type == RT_PRIM_CYLINDER) return D3(0.5, 0.5, 0.5);
-#endif
     switch (p.type) {
         case RT_PRIM_SPHERE: {
             d3 I = unit(c.C - T3(p, TF_SPH_O));
@@ -1499,11 +1478,7 @@ DEV d3 texture_color(SCREF sc, uint32_t flags, const DevShade& p, const Hit& c, 
             d3 O1 = T3(p, TF_CYL_O1), O2 = T3(p, TF_CYL_O2);
             if (!c.front) {
                 d3 cp = c.C - O1;
-#ifdef RT_ABLATE_ATAN2  // timing experiments only
-                double ang = cp.z * 0.1 + cp.x * 0.2;
-#else
                 double ang = rt_atan2(cp.z, cp.x);  // atan2 of CR/Primitive.cu:58, see rt_atan2
-#endif
                 if (ang < 0) ang += 2 * M_PI;
                 u = ang / (2 * M_PI);
                 v = dot(c.C - O1, T3(p, TF_CYL_AX)) / p.tf[TF_CYL_LEN];
@@ -1519,9 +1494,6 @@ DEV d3 texture_color(SCREF sc, uint32_t flags, const DevShade& p, const Hit& c, 
             return D3(0, 0, 0);
     }
     ctr.texfetch++;
-#ifdef RT_ABLATE_TEXFETCH  // timing experiments only
-    return D3(u - floor(u), v - floor(v), 0.5);
-#endif
     return smooth_color(sc, flags, p, u, v);
 }
 

@@ -400,10 +400,12 @@ extern "C" int rt_set_tree_builder(int which) {
 }
 
 extern "C" int rt_scene_waves_per_simd(const rt_scene* s) { return s ? s->waves : 0; }
+#ifdef RT_EXPERIMENTS
 extern "C" int rt_scene_deferred_shadows(const rt_scene* s, int* fallbacks) {
     if (fallbacks) *fallbacks = s ? s->defer_fallbacks : 0;
     return s ? s->defer : 0;
 }
+#endif
 extern "C" double rt_scene_tree_build_ms(const rt_scene* s) { return s ? (double)s->tree_build_ms : 0.0; }
 extern "C" int rt_scene_shared_walk(const rt_scene* s, double* plain_ms, double* shared_ms) {
     if (!s) return -1;

@@ -45,7 +45,10 @@ class DeviceScene:
 
     @property
     def deferred_shadows(self):
-        """(in use, calls that fell back to the one-kernel render) of the three-kernel render."""
+        """(in use, calls that fell back to the one-kernel render) of the three-kernel render; (0, 0) with a library that
+        was not built with -DRT_EXPERIMENTS (the shipped one): it has no such render."""
+        if not abi.has_experiments(self._lib):
+            return 0, 0
         n = C.c_int(0)
         on = int(self._lib.rt_scene_deferred_shadows(self._h, C.byref(n)))
         return on, n.value

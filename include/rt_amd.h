@@ -269,13 +269,16 @@ int rt_scene_shared_walk(const rt_scene* scene, double* plain_ms, double* shared
  * only where shadow rays walking meshes carry the frame; scenes with several meshes or more than 65536 triangles get it
  * (RT_AMD_WAVES=3|4 overrides).  Returns the build this scene's pruned renders use.  No counterpart in the reference. */
 int rt_scene_waves_per_simd(const rt_scene* scene);
-/* Pruned renders have a second form: three lean kernels instead of one large one.  The paths are traced without their shadow
- * rays (a record per ray says what was hit and which shadow rays are still open), a second kernel traces all shadow rays, a
- * third computes the colours from the records; same image bit for bit.  It needs about 0.9 KB of device memory per path of a
- * launch (launches are cut at 2^25 paths) and at most 4 lamps.  Returns whether this scene's pruned renders use it
- * (RT_AMD_DEFER=0|1 in the environment at rt_scene_create decides) and, in *fallbacks, how many calls had to be rendered
+#ifdef RT_EXPERIMENTS
+/* Only in libraries built with -DRT_EXPERIMENTS (A/B timing builds, tools/ab.sh), not in the shipped one.  Pruned renders have
+ * a second form there: three lean kernels instead of one large one.  The paths are traced without their shadow rays (a record per
+ * ray says what was hit and which shadow rays are still open), a second kernel traces all shadow rays, a third computes the
+ * colours from the records; same image bit for bit, measured slower on every configuration.  It needs about 0.9 KB of device
+ * memory per path of a launch (launches are cut at 2^25 paths) and at most 4 lamps.  Returns whether this scene's pruned renders
+ * use it (RT_AMD_DEFER=0|1 in the environment at rt_scene_create decides) and, in *fallbacks, how many calls had to be rendered
  * again by the one kernel because a record buffer was too small.  No counterpart in the reference. */
 int rt_scene_deferred_shadows(const rt_scene* scene, int* fallbacks);
+#endif
 
 /* Upload a scene: one slab, one copy.  Replaces createCudaSceneFromCPUScene
  * (CR/Renderer_CUDA.cpp:298-335). */
@@ -297,16 +300,16 @@ int rt_render_tile(rt_scene* scene, const rt_settings* settings, int tex_w, int 
 int rt_render_frame(rt_scene* scene, const rt_settings* settings, int tex_w, int tex_h, int cam_w,
                     int cam_h, int tile, int part, int n_parts, uint8_t* rgba, rt_stats* stats);
 
-/* rt_render_tile for callers that cannot allocate device memory: code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same kernels and
- * same result as rt_render_tile, but the work buffers (queue heads, counters, the rectangle's list of
- * 8x8 pixel blocks, the path colours of one launch) live in a fixed 12.1 MiB array in device memory
- * that every GPU the library runs on holds until the process ends; nothing is allocated or freed by
- * this call.  `rgba_device` must be device memory on the scene's GPU (tex_w*tex_h*4 bytes).  Limits
- * (RT_ERR_LIMIT beyond them): the rectangle may hold at most 16384 blocks of 8x8 pixels (about 1 M
- * pixels) and settings->spp at most 8192; calls with more than 2^19 paths run as several launches.
- * All calls on one GPU share that GPU's array: calls that overlap in time (threads, streams, scenes)
- * race.  Blocking, like every other call. */
+/* rt_render_tile for callers that cannot allocate device memory: tight serving loops that must not touch the allocator,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference.  Same kernels and same result as rt_render_tile, but the
+ * work buffers (queue heads, counters, the rectangle's list of 8x8 pixel blocks, the path colours of one launch) live in a fixed
+ * 12.1 MiB array in device memory that every GPU the library runs on holds until the process ends; nothing is allocated or freed
+ * by this call.  `rgba_device` must be device memory on the scene's GPU (tex_w*tex_h*4 bytes).  Limits (RT_ERR_LIMIT beyond
+ * them): the rectangle may hold at most 16384 blocks of 8x8 pixels (about 1 M pixels) and settings->spp at most 8192; calls with
+ * more than 2^19 paths run as several launches.  All calls on one GPU share that GPU's array: calls of one process that overlap
+ * in time (other threads, other scenes) are serialised by a per-device lock; two processes have an array each.  Blocking, like
+ * every other call: it copies the block list to the device, reads the counters back and synchronises the stream, so it cannot
+ * be recorded into a HIP graph (it allocates nothing, which is all it promises). */
 int rt_render_tile_noalloc(rt_scene* scene, const rt_settings* settings, int tex_w, int tex_h, int cam_w,
                            int cam_h, int x0, int y0, int w, int h, uint8_t* rgba_device, rt_stats* stats);
 
@@ -355,6 +358,9 @@ int rt_trace_primary(rt_scene* scene, const rt_settings* settings, int tex_w, in
                      int32_t* hit_leaf, uint32_t* visit_log, uint32_t* visit_count, int visit_cap);
 
 const char* rt_last_error(void);
+/* A short hash of the sources and compiler flags this library was built from ("unidentified" if the build script passed none).
+ * Lets a measurement harness refuse profiler counters that were collected with another build.  No counterpart in the reference. */
+const char* rt_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -148,7 +148,9 @@ def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
             flags ^= abi.RT_F_MESH_RAW_DIR
         st = orc.settings(spp=SPP, dof=bool(seed % 2), focal=9.0, aperture=1.0, seed=seed + 1, flags=flags | abi.RT_F_STRICT_TRAVERSAL)
         # the pruned walk's trees from each of the three builders in turn (scenes without meshes have none)
-        with DeviceScene(hs, device=0, tree_builder=("host", "device_sah", "device")[seed % 3]) as ds:
+        # (the builder turns over with seed // 3, the preset with seed % 3, the oracle sample every 13th scene: every preset meets
+        # every builder, and the oracle sees all of those pairs)
+        with DeviceScene(hs, device=0, tree_builder=("host", "device_sah", "device")[(seed // 3) % 3]) as ds:
             ds.check_trees()
             strict, ss = ds.render_frame(st, W, H)
             st.flags = flags
@@ -163,7 +165,7 @@ def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
                     why = f"{k}: pruned {getattr(fs, k)} != reference-order {getattr(ss, k)}"
             if fs.rays_shadow_traced > fs.rays_shadow or ss.rays_shadow_traced != ss.rays_shadow:
                 why = "traced shadow rays inconsistent"
-        if why is None and seed % 12 == 0:  # the oracle on a sample: both GPU modes could be wrong together
+        if why is None and seed % 13 == 0:  # the oracle on a sample: both GPU modes could be wrong together
             st.flags = flags | abi.RT_F_STRICT_TRAVERSAL
             ref, _, os_ = orc.render(hs, st, W, H)
             d = np.abs(strict[..., :3].astype(int) - ref[..., :3].astype(int))
@@ -177,4 +179,4 @@ def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
             failures.append((seed, why))
     abi.load_library().rt_set_tree_builder(0)
     assert not failures, f"{len(failures)} of {N_SCENES} scenes failed (scene files kept in gpurun_out/fuzz_fail_<seed>.txt): {failures[:5]}"
-    assert checked_oracle >= N_SCENES // 12
+    assert checked_oracle >= N_SCENES // 13

@@ -100,7 +100,7 @@ def test_renderer_cli_with_a_gpu_count(tmp_path):
     assert outs[0] == outs[1]
 
 
-def test_bench_two_and_three_ranks_rehearsal():
+def test_bench_two_three_and_eight_ranks_rehearsal():
     """`bench.py --gpus N` end to end on the one-GPU box: it starts its own ranks, every rank renders its tiles (on GPU 0),
     the packs are gathered (over gloo, host copies) and rank 0's assembled frame must equal a single-rank render."""
     import json
@@ -109,13 +109,18 @@ def test_bench_two_and_three_ranks_rehearsal():
     from helpers import ROOT
     env = dict(os.environ, RT_BENCH_REHEARSE="1")
     env.pop("WORLD_SIZE", None)
-    for n, cfg in ((2, ["--config", "c1"]), (3, ["--config", "headline", "--width", "200", "--height", "136", "--spp", "2"])):
+    for n, cfg in ((2, ["--config", "c1"]), (3, ["--config", "headline", "--width", "200", "--height", "136", "--spp", "2"]),
+                   (8, ["--config", "headline", "--width", "480", "--height", "272", "--spp", "2"])):  # the rank count of a full node
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                             "--no-strict"] + cfg, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
         assert p.returncode == 0, p.stderr[-3000:]
         line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == n and line["value"] > 0
         assert line["rehearsal"]["frame_matches_single_rank"] and line["rehearsal"]["rays_match_single_rank"], line["rehearsal"]
+        # a multi-rank line explains its own efficiency: every rank's kernel time and its time in the exchange
+        roof = line["roofline"]
+        assert len(roof["kernel_ms_per_rank"]["all"]) == n and roof["kernel_ms_per_rank"]["min"] > 0
+        assert len(roof["exchange_ms_per_rank"]) == n and roof["exchange_ms"] > 0 and roof["frac"] is None
 
 
 def test_exchange_calls_over_rccl_with_one_rank(tmp_path):

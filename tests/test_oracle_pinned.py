@@ -209,3 +209,13 @@ def test_bilinear_taps_of_both_renderers_on_one_texel_quad():
     # channel 2: 0, uchar(uchar(63.75) * .25) = 15, uchar(uchar(191.25) * .75) = 143, 0
     assert gpu[2] == (15 + 143) / 256
     assert gpu == _fetch(tex, abi.RT_MODE_GPU_REF, u, v)
+
+
+def test_audit_cites_the_oracle_where_it_is():
+    """oracle/AUDIT.md maps every statement group of the reference's .cu files to line ranges of cpu_ref.c: they must still
+    lie inside the functions they name."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_audit_lines.py")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout

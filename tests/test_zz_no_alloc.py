@@ -51,3 +51,53 @@ def test_noalloc_entry_point_matches_render_tile():
         with pytest.raises(abi.RtError) as e:
             ds.render_tile_noalloc(st, 96, 64, (0, 0, 8, 8), np.zeros((64, 96, 4), dtype=np.uint8))
         assert "device memory" in str(e.value)
+
+
+def test_noalloc_calls_from_two_threads_on_one_gpu_take_turns():
+    """Two host threads, each with a scene and a stream of its own, call rt_render_tile_noalloc at the same time on one GPU.
+    Both work in that GPU's one fixed array; the library's per-device lock makes them take turns, so every image must equal
+    what rt_render_tile gives for the same call."""
+    import threading
+
+    import torch
+    from cuda_raytracing_amd.device import DeviceScene
+    jobs = [("c4_lucy", 1.35, [(256, 160, (0, 0, 256, 160), 3), (128, 96, (5, 7, 100, 80), 6), (256, 160, (16, 8, 200, 150), 2)]),
+            ("c3_orange", 14.5, [(200, 120, (0, 0, 200, 120), 4), (256, 144, (9, 3, 240, 130), 2), (96, 64, (0, 0, 96, 64), 8)])]
+    scenes = [DeviceScene(HostScene(os.path.join(SCENES, name + ".txt")), device=0) for name, _, _ in jobs]
+    try:
+        want = []
+        for ds, (_, focal, calls) in zip(scenes, jobs):
+            want.append([ds.render_tile(orc.settings(spp=spp, dof=True, focal=focal, aperture=1.0, seed=4, flags=abi.RT_MODE_GPU_REF), W, H, rect)[0]
+                         for (W, H, rect, spp) in calls])
+        got = [[None] * len(calls) for _, _, calls in jobs]
+        errors = []
+        start = threading.Barrier(len(jobs))
+
+        def worker(k):
+            try:
+                ds, (_, focal, calls) = scenes[k], jobs[k]
+                stream = torch.cuda.Stream(device=0)
+                ds.set_stream(stream.cuda_stream)  # the render stream belongs to the calling thread
+                start.wait()
+                for rounds in range(3):  # the same calls three times over, to give the two threads time to collide
+                    for i, (W, H, rect, spp) in enumerate(calls):
+                        st = orc.settings(spp=spp, dof=True, focal=focal, aperture=1.0, seed=4, flags=abi.RT_MODE_GPU_REF)
+                        out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+                        ds.render_tile_noalloc(st, W, H, rect, out)
+                        got[k][i] = out.cpu().numpy()
+                ds.set_stream(0)
+            except Exception as e:  # noqa: BLE001  (reported by the main thread)
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for k in range(len(jobs)):
+            for i in range(len(jobs[k][2])):
+                assert np.array_equal(got[k][i], want[k][i]), (jobs[k][0], i)
+    finally:
+        for ds in scenes:
+            ds.close()
