@@ -420,8 +420,9 @@ __global__ __launch_bounds__(256, RT_SHADOW_WAVES) void shadow_kernel(RenderPara
                     target = light_sample(L, fa, fb);
                 }
                 bool clear = false;
-                if (SHARE) clear = shadow_clear_shared(sc, P.flags, act, C, target, (int)J.crashed, L.light_primitive, J.cand, ctr, stk, xch);
-                else if (act) clear = shadow_clear<false>(sc, P.flags, C, target, (int)J.crashed, L.light_primitive, J.cand, ctr, stk);
+                const unsigned long long wave_prims = wave_or_u64(act ? J.cand : 0ull);
+                if (SHARE) clear = shadow_clear_shared(sc, P.flags, act, C, target, J.cand, wave_prims, ctr, stk, xch);
+                else if (act) clear = shadow_clear<false>(sc, P.flags, C, target, (int)J.crashed, L.light_primitive, J.cand, wave_prims, ctr, stk);
                 // runs of lanes that belong to one job
                 const uint32_t job_before = (uint32_t)__shfl_up((int)job, 1, 64);
                 const bool leader = act && (lane == 0 || job_before != job);

@@ -203,7 +203,8 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
             const int si = item - r * n_l;
             const int owner = __shfl(owner_tbl, r, 64);
             const d3 C = shfl_d3(h.C, owner);
-            const int crashed = __shfl(h.prim, owner, 64);
+            // (the pruned tests read the owner's candidate mask, which already leaves out the shaded primitive and the lamp's own)
+            const int crashed = (STRICT || sc.n_prims > 64) ? __shfl(h.prim, owner, 64) : -1;
             const uint32_t opix = __shfl(pixel, owner, 64), osmp = __shfl(smp, owner, 64), odraw = __shfl(draw, owner, 64);
             const unsigned long long ocand = STRICT ? ~0ull : __shfl(cand, owner, 64);
             bool clear = false;
@@ -232,10 +233,12 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
                 }
             }
             RT_LAP(ctr, PF_RNG);
+            // the primitives some ray of this chunk has to be tested against: the tests below loop over these only
+            const unsigned long long chunk_prims = STRICT ? ~0ull : wave_or_u64(act ? ocand : 0ull);
             if (SHARE && stk != nullptr) {
-                clear = shadow_clear_shared(sc, P.flags, act, C, target, crashed, L.light_primitive, ocand, ctr, stk, xch);
+                clear = shadow_clear_shared(sc, P.flags, act, C, target, ocand, chunk_prims, ctr, stk, xch);
             } else if (act) {
-                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, ctr, stk);
+                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, chunk_prims, ctr, stk);
             }
             RT_LAP(ctr, PF_SH_PRIMS);
             const unsigned long long cm = __ballot(clear);
@@ -287,10 +290,29 @@ DEV uint32_t div_by(uint32_t n, uint32_t d, double inv) {
     return q;
 }
 
+// colour sum of frame k in the LDS part of the frame stack (six words; see trace_stream)
+DEV void st_frame_acc(uint32_t* fl, int k, d3 a) {
+    uint32_t* p = fl + k * 7 * 64;
+    p[0] = (uint32_t)__double2loint(a.x), p[64] = (uint32_t)__double2hiint(a.x);
+    p[128] = (uint32_t)__double2loint(a.y), p[192] = (uint32_t)__double2hiint(a.y);
+    p[256] = (uint32_t)__double2loint(a.z), p[320] = (uint32_t)__double2hiint(a.z);
+}
+DEV d3 ld_frame_acc(const uint32_t* fl, int k) {
+    const uint32_t* p = fl + k * 7 * 64;
+    return D3(__hiloint2double((int)p[64], (int)p[0]), __hiloint2double((int)p[192], (int)p[128]), __hiloint2double((int)p[320], (int)p[256]));
+}
+
 // All paths of a launch.  The wave keeps up to 64 paths in flight, one per lane; lanes whose path has ended wait
 // until enough of them are idle, then take the next unstarted paths of the launch together ("path regeneration").
-template <bool STRICT, bool SHARE>
-DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* xch) {
+// FLDS = how many frames of the frame stack (the two at its bottom: depth 1 and 2) keep their colour sum and primitive word in
+// LDS instead of scratch; `fl` = this lane's column of that area, word w of frame k at fl[(k * 7 + w) * 64].  Most paths never get
+// deeper, so most pushes and pops then stay on the chip (scratch is per-lane memory behind L2: every frame written there is
+// HBM traffic, and a pop waits for it to come back).
+#ifndef RT_FRAME_LDS
+#define RT_FRAME_LDS 2
+#endif
+template <bool STRICT, bool SHARE, int FLDS>
+DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* xch, uint32_t* fl) {
     // The launch parameters and the scene record are read from the kernel-argument segment where they are needed, through a
     // pointer the compiler has to take as new at the start of every stage (RT_FRESH): otherwise all ~100 words of them are
     // loaded at the kernel's entry, kept for its whole life, and - there being no scalar registers for that - parked in lanes
@@ -422,7 +444,8 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
                 const bool has_refl = m.refl > RT_EPS, has_refr = m.refr > RT_EPS;
                 if (has_refl || has_refr) {
                     const int k = sp;
-                    f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
+                    if (FLDS > 0 && k < FLDS) st_frame_acc(fl, k, acc);
+                    else f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
                     if (has_refl && has_refr) {  // only a refraction that waits for the reflection subtree needs the hit again
                         f_C[k][0] = h.C.x, f_C[k][1] = h.C.y, f_C[k][2] = h.C.z;
                         f_N[k][0] = h.N.x, f_N[k][1] = h.N.y, f_N[k][2] = h.N.z;
@@ -458,7 +481,8 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
                         nd = refract(d, h.N, n);
                     }
                     top = (uint32_t)h.prim | st << 28;
-                    f_prim[k] = top;
+                    if (FLDS > 0 && k < FLDS) fl[(k * 7 + 6) * 64] = top;
+                    else f_prim[k] = top;
                     sp++;
                     o = h.C;
                     d = nd;
@@ -489,11 +513,12 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
                     d3 tr = D3(rt_exp(ab.x), rt_exp(ab.y), rt_exp(ab.z));
                     contrib = mulv(result, tr) * m.refr;
                 }
-                d3 acc = D3(f_acc[k][0], f_acc[k][1], f_acc[k][2]) + contrib;
+                const bool in_lds = FLDS > 0 && k < FLDS;
+                d3 acc = (in_lds ? ld_frame_acc(fl, k) : D3(f_acc[k][0], f_acc[k][1], f_acc[k][2])) + contrib;
                 if ((st & ST_REFL) && (st & ST_PENDING_REFR)) {
-                    f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z;
                     top = (fp & 0x0fffffffu) | ((st & ST_FRONT) | ST_REFR) << 28;
-                    f_prim[k] = top;
+                    if (in_lds) st_frame_acc(fl, k, acc), fl[(k * 7 + 6) * 64] = top;
+                    else f_acc[k][0] = acc.x, f_acc[k][1] = acc.y, f_acc[k][2] = acc.z, f_prim[k] = top;
                     double n = m.rindex;
                     if (st & ST_FRONT) n = 1.0 / n;
                     d3 V = D3(f_V[k][0], f_V[k][1], f_V[k][2]), N = D3(f_N[k][0], f_N[k][1], f_N[k][2]);
@@ -503,7 +528,7 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
                 } else {
                     result = clamp1(acc);
                     sp--;
-                    if (sp > 0) top = f_prim[sp - 1];
+                    if (sp > 0) top = (FLDS > 0 && sp - 1 < FLDS) ? fl[((sp - 1) * 7 + 6) * 64] : f_prim[sp - 1];
                 }
             }
         }
@@ -528,11 +553,15 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
 // walking meshes dominate, because that loop waits on dependent node loads (c5_final at 32 spp: 182 -> 169 ms/frame).
 template <bool STRICT, int SHADE_CAP, bool SHARE, int WAVES = RT_WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams) {
+    // frames kept in LDS: only where three blocks still fit a CU's 160 KB with them (small shading table, three-waves build)
+    constexpr int FLDS = (!STRICT && SHADE_CAP == 16 && WAVES == 3) ? RT_FRAME_LDS : 0;
+    __shared__ uint32_t s_frames[FLDS > 0 ? 4 * FLDS * 7 * 64 : 1];
+    uint32_t* fl = FLDS > 0 ? s_frames + (threadIdx.x >> 6) * (FLDS * 7 * 64) + (threadIdx.x & 63) : nullptr;
     RPREF P = KERNARG(RenderParams);
     const int lane = lane_id();
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
-    __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK * 64];
-    uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK * 64) + lane;
+    __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK_ROWS * 64];
+    uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK_ROWS * 64) + lane;
     __shared__ DevShade s_shade[SHADE_CAP > 0 ? SHADE_CAP : 1];
     const DevShade* shade = P.sc.shade;
     if (SHADE_CAP > 0) {  // every hit reads a few fields of its record, one after another
@@ -557,7 +586,7 @@ __global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams) {
     constexpr int XCH_WORDS = RT_SHARE_CLOSEST ? 448 : 192;
     __shared__ __attribute__((aligned(8))) uint32_t s_xch[SHARE ? 4 * XCH_WORDS : 2];
     uint32_t* xch = SHARE ? s_xch + (threadIdx.x >> 6) * XCH_WORDS : nullptr;
-    trace_stream<STRICT, SHARE>(P, shade, ctr, stk, xch);
+    trace_stream<STRICT, SHARE, FLDS>(P, shade, ctr, stk, xch, fl);
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_REFILL);
     if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);
@@ -1140,7 +1169,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
             else hipLaunchKernelGGL((path_kernel<0>), gp, t, 0, g_stream, P, D);
             HIPCHK(hipGetLastError());
             const dim3 gs((unsigned)((uint64_t)s->cus * RT_SHADOW_WAVES));
-            if (s->dev.mesh_scale_max > 0.0) hipLaunchKernelGGL((shadow_kernel<true>), gs, t, 0, g_stream, P, D);
+            if (s->dev.mesh_scale_max > 0.0 && P.sc.n_prims <= 64) hipLaunchKernelGGL((shadow_kernel<true>), gs, t, 0, g_stream, P, D);  // (the shared test reads 64-bit candidate masks)
             else hipLaunchKernelGGL((shadow_kernel<false>), gs, t, 0, g_stream, P, D);
             HIPCHK(hipGetLastError());
             const dim3 gf((unsigned)std::min<uint64_t>(want_blocks, (uint64_t)s->cus * 8));

@@ -54,6 +54,7 @@ enum {
 #ifndef RT_STACK
 #define RT_STACK 32  // per-lane traversal stack entries (LDS); a mesh whose collapsed tree needs more uses the stackless walk
 #endif
+#define RT_STACK_ROWS RT_STACK
 struct DevNode4 {    // 128 bytes
     float lo[3][4], hi[3][4];  // [axis][child]
     uint32_t child[4];
@@ -1182,7 +1183,14 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
 #pragma unroll
     for (int k = 0; k < 3; k++) iD[k] = fabs(Da[k]) > 1e-200 ? approx_rcp(Da[k]) : 0.0;
     unsigned long long m = 0;
+    // only the primitives in some lane's cell mask are looked at (the lanes that are here: the call site is divergent)
+#ifdef RT_X_LC
     for (int j = 0; j < sc.n_prims; j++) {
+#else
+    const unsigned long long in_scene = sc.n_prims >= 64 ? ~0ull : (1ull << sc.n_prims) - 1ull;
+    for (unsigned long long todo = wave_or_u64(cell) & in_scene; todo != 0ull; todo &= todo - 1ull) {
+        const int j = __builtin_ctzll(todo);
+#endif
         if (__ballot(((cell >> j) & 1ull) != 0ull && (full & ~skip) == 0ull) == 0ull) continue;  // no lane still needs this primitive
         const DevGeom RT_CONST& g = GEOM(sc)[j];
         bool may = ((cell >> j) & 1ull) != 0ull;
@@ -1279,24 +1287,31 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
 
 // ---- one shadow ray: CR/Shade.cu:36-46,64-75,94-105, CR/Light.cpp:35-40,67-78 ----------------
 // true = nothing between C and target.  A primitive occludes if dist - its_hit_distance > 1e-6.
+// `cand` = the primitives this ray has to be tested against (pruned mode, scenes of at most 64 primitives: the shaded one and the
+// lamp's own are already left out of it), `wave_prims` = the union of `cand` over the rays of the wave (the same in every lane):
+// the loop visits only those.  Reference-order mode and scenes of more than 64 primitives test every primitive but the skipped.
 template <bool STRICT>
 DEV bool shadow_clear(SCREF sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
-                      Counters& ctr, uint32_t* stk) {
+                      unsigned long long wave_prims, Counters& ctr, uint32_t* stk) {
     const d3 Vv = target - C;
     const double dist = module(Vv);
     const d3 V = Vv / dist;                                  // = normalize(Vv)
     const d3 dm = (flags & RT_F_MESH_RAW_DIR) ? Vv : V;
     uint32_t dummy_n = 0;
     const bool self_skip = (flags & RT_F_SHADOW_SELF_SKIP) != 0;
+    const bool masked = !STRICT && sc.n_prims <= 64;
+    unsigned long long todo = masked ? wave_prims : ~0ull;
     for (int j = 0; j < sc.n_prims; j++) {
-        if (!STRICT) {
+        if (masked) {
             // primitives that cannot lie between any lane's shaded point and its lamp are skipped by the whole wave
-            const bool mine = j >= 64 || ((cand >> j) & 1ull);
-            if (__ballot(mine) == 0ull) continue;
-            if (!mine) continue;
+            if (todo == 0ull) break;
+            j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            if (!((cand >> j) & 1ull)) continue;
+        } else {
+            if (self_skip && j == crashed) continue;
+            if (j == light_prim) continue;
         }
-        if (self_skip && j == crashed) continue;
-        if (j == light_prim) continue;
         const DevGeom RT_CONST& g = GEOM(sc)[j];
         Hit tmp;
         double t = RT_BIG_DIST;
@@ -1332,18 +1347,19 @@ DEV bool shadow_clear(SCREF sc, uint32_t flags, d3 C, d3 target, int crashed, in
 
 // shadow_clear for the pruned mode, called by all 64 lanes (`act` = this lane has a ray): the meshes are walked with
 // mesh_anyhit_shared, so lanes without a ray, or whose ray is already known to be occluded, help the others.
-DEV bool shadow_clear_shared(SCREF sc, uint32_t flags, bool act, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
+// (scenes of at most 64 primitives only: `cand` and `wave_prims` as in shadow_clear)
+DEV bool shadow_clear_shared(SCREF sc, uint32_t flags, bool act, d3 C, d3 target, unsigned long long cand, unsigned long long wave_prims,
                              Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const d3 Vv = target - C;
     const double dist = module(Vv);
     const d3 V = Vv / dist;  // = normalize(Vv)
     const d3 dm = (flags & RT_F_MESH_RAW_DIR) ? Vv : V;
     uint32_t dummy_n = 0;
-    const bool self_skip = (flags & RT_F_SHADOW_SELF_SKIP) != 0;
     bool alive = act;  // has a ray that nothing has occluded so far
     int sp = 0;        // roots of the meshes the ray may enter, on this lane's stack
-    for (int j = 0; j < sc.n_prims; j++) {
-        const bool mine = alive && (j >= 64 || ((cand >> j) & 1ull)) && !(self_skip && j == crashed) && j != light_prim;
+    for (unsigned long long todo = wave_prims; todo != 0ull; todo &= todo - 1ull) {
+        const int j = __builtin_ctzll(todo);
+        const bool mine = alive && ((cand >> j) & 1ull);
         if (__ballot(mine) == 0ull) continue;
         if (!mine) continue;
         const DevGeom RT_CONST& g = GEOM(sc)[j];
