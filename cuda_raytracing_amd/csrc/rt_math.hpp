@@ -120,8 +120,10 @@ DEV void det_sincos(double x, double& sn, double& cs) {
 DEV void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c[0]), l0 = 0xD2511F53u * c[0];
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c[2]), l1 = 0xCD9E8D57u * c[2];
+        // both halves of each product from one 32 x 32 -> 64 bit multiply (integer multiplies run at a quarter of the vector rate)
+        const unsigned long long p0 = (unsigned long long)c[0] * 0xD2511F53ull, p1 = (unsigned long long)c[2] * 0xCD9E8D57ull;
+        uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+        uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         uint32_t n0 = h1 ^ c[1] ^ k0, n2 = h0 ^ c[3] ^ k1;
         c[0] = n0, c[1] = l1, c[2] = n2, c[3] = l0;
         k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Full-size golden frames of bench configurations from the CPU oracle (oracle/liboracle.so), with the settings `bench.py`
 renders them with (semantics preset gpu_ref, seed 1): headline = c4_lucy 1920x1080x32 spp, c2 = c2_textured_mirror
-1280x720x128, c3 = c3_orange 1920x1080x64, c5x4 = c5_final 1920x1080 at 4 samples per pixel (its 128 would take the oracle hours), c4bands = c4_lucy 3840x2160x32 on
+1280x720x128, c3 = c3_orange 1920x1080x64, c5x4 = c5_final 1920x1080 at 4 samples per pixel, c5 = the same at its full 128 (over an hour of oracle), c4bands = c4_lucy 3840x2160x32 on
 34 bands of 8 rows spread evenly over the frame (rows 64 k + 24 .. 64 k + 31; the whole frame would take the oracle an hour).  Every ray is traced in reference order (minutes on 8 cores), so the ray / node /
 triangle totals of a frame are the reference's.  Writes tests/golden/render/<scene>_<height>p<spp>.npz: the 8-bit image
 (R, G, B planes, row 0 = bottom) and the counters.
-Usage: python tools/make_fullframe_golden.py [--config headline|c2|c3|c5x4|c4bands] [--threads N]"""
+Usage: python tools/make_fullframe_golden.py [--config headline|c2|c3|c5x4|c5|c4bands] [--threads N]"""
 import argparse
 import os
 import sys
@@ -53,13 +53,14 @@ def bands(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c5x4", "c4bands"])
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c5x4", "c5", "c4bands"])
     args = ap.parse_args()
     if args.config == "c4bands":
         return bands(args)
     name, W, H, spp, aperture, focal = {"headline": ("c4_lucy", 1920, 1080, 32, 1.0, 1.35), "c2": ("c2_textured_mirror", 1280, 720, 128, 10.0, 10.2),
                                         "c3": ("c3_orange", 1920, 1080, 64, 10.0, 14.5),
-                                        "c5x4": ("c5_final", 1920, 1080, 4, 150.0, 168.0)}[args.config]  # C5's frame at 4 of its 128 samples
+                                        "c5x4": ("c5_final", 1920, 1080, 4, 150.0, 168.0),  # C5's frame at 4 of its 128 samples
+                                        "c5": ("c5_final", 1920, 1080, 128, 150.0, 168.0)}[args.config]  # the whole of C5: about 75 minutes on 8 cores
     args.out = os.path.join(ROOT, "tests", "golden", "render", f"{name}_{H}p{spp}.npz")
     hs = HostScene(os.path.join(SCENE_DIR, name + ".txt"))
     st = orc.settings(spp=spp, dof=True, focal=focal, aperture=aperture, seed=1, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
