@@ -95,7 +95,9 @@ DEV void diffusion_defer(RPREF P, const DeferParams& D, const DevShade* shade, b
                 unsigned long long full, skip = 0ull;  // primitives the shadow test leaves out for this point and lamp
                 if ((P.flags & RT_F_SHADOW_SELF_SKIP) && h.prim < 64) skip |= 1ull << h.prim;
                 if (L.light_primitive >= 0 && L.light_primitive < 64) skip |= 1ull << L.light_primitive;
-                cand = light_candidates(sc, P.flags, h.C, L, l, skip, full) & ~skip;
+                const unsigned long long cell = candidate_cell(sc, h.C, l, skip, full);
+                if (full != 0ull) cand = full;  // the whole cell lies in an umbra
+                else cand = light_candidates(sc, P.flags, h.C, L, skip, cell, ~0ull, full) & ~skip;
                 if (cand == 0ull) work = false, cnt = n_l;                      // nothing can stand in between
                 else if ((full & cand) != 0ull) work = false, cnt = 0;          // in the umbra of one primitive
             }

@@ -121,6 +121,9 @@ DEV uint32_t to_u8(double c) {
 
 // `pp` = the address of the launch parameters again, as a value the compiler knows nothing about: loads through it cannot be
 // moved above this point, so what a stage needs of the parameters is loaded (scalar loads, cached) when the stage begins
+#ifndef RT_X_OUTCOME
+#define RT_X_OUTCOME 0
+#endif
 #define RT_FRESH()                   \
     do {                             \
         pp = &P_in;                  \
@@ -129,7 +132,7 @@ DEV uint32_t to_u8(double c) {
 
 // ---- CalnDiffusion for every lane that needs it, shadow rays dealt over the wave ---------------
 // CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
-template <bool STRICT, bool SHARE>
+template <bool STRICT, bool SHARE, bool CONE>
 DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
                       uint32_t pixel, uint32_t smp, Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const RenderParams RT_CONST* pp;
@@ -165,16 +168,40 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
             ctr.rays_shadow += (uint32_t)n_l;
             dt = dot(unit(d3{L.O.x, L.O.y, L.O.z} - h.C), h.N);
         }
-        if (!STRICT && need) {
-            if (!(dt > RT_EPS)) {
-                work = false;
-            } else {
-                unsigned long long full, skip = 0ull;  // primitives the shadow test leaves out for this point and lamp
+        if (!STRICT) {
+            // (every lane goes through here, the ones with nothing to ask too: the unions below are taken over the whole wave)
+            const bool ask = need && dt > RT_EPS;
+            if (need && !ask) work = false;
+            unsigned long long full = 0ull, skip = 0ull, cell = 0ull;  // skip: the primitives the shadow test leaves out for this point and lamp
+            if (ask) {
                 if ((P.flags & RT_F_SHADOW_SELF_SKIP) && h.prim < 64) skip |= 1ull << h.prim;
                 if (L.light_primitive >= 0 && L.light_primitive < 64) skip |= 1ull << L.light_primitive;
-                cand = light_candidates(sc, P.flags, h.C, L, l, skip, full) & ~skip;
+                cell = candidate_cell(sc, h.C, l, skip, full);
+                if (full != 0ull) work = false, cnt = 0, cell = 0ull;  // the whole cell lies in the umbra of one primitive: no sample is visible
+            }
+            const unsigned long long wave_cells = wave_or_u64(cell);
+            if (ask && full == 0ull) {
+                cand = light_candidates(sc, P.flags, h.C, L, skip, cell, wave_cells, full) & ~skip;
                 if (cand == 0ull) work = false, cnt = n_l;
                 else if ((full & cand) != 0ull) work = false, cnt = 0;  // in the umbra of one primitive: no sample is visible
+            }
+            // A mesh's root box is mostly empty: before a point's samples go to the tracer because of a mesh, look at the boxes
+            // further down its tree (mesh_cone_may).  Not for point lamps: one ray each, the look would cost as much as the ray.
+            if (CONE && stk != nullptr && !point && sc.n_prims <= 64) {
+                const unsigned long long mine = work ? cand & sc.mesh_mask : 0ull;
+                const unsigned long long meshes = wave_or_u64(mine);
+                if (meshes != 0ull) {
+                    RT_FRESH();
+                    const d3 Dl = d3{L.O.x, L.O.y, L.O.z} - h.C;
+                    const double Rl = lamp_reach(L);
+                    const double smax = (P.flags & RT_F_MESH_RAW_DIR) ? (module(Dl) + Rl) * (1.0 + 1e-6) : 1.0;  // as in light_candidates
+                    for (unsigned long long todo = meshes; todo != 0ull; todo &= todo - 1ull) {
+                        const int j = __builtin_ctzll(todo);
+                        const DevGeom RT_CONST& g = GEOM(sc)[j];
+                        if (((mine >> j) & 1ull) && g.aux2 && !mesh_cone_may(sc, g, h.C, Dl, Rl, smax, stk)) cand &= ~(1ull << j);
+                    }
+                    if (work && cand == 0ull) work = false, cnt = n_l;
+                }
             }
         }
         RT_LAP(ctr, PF_CAND);
@@ -209,7 +236,7 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
             const unsigned long long ocand = STRICT ? ~0ull : __shfl(cand, owner, 64);
             bool clear = false;
 #ifdef RT_UTIL_COUNTERS
-            if (act && !STRICT && RT_PROBE_KINDS == 3) {  // which kinds of primitives make this ray necessary
+            if (act && !STRICT && RT_PROBE_KINDS == 3 && !RT_X_OUTCOME) {  // which kinds of primitives make this ray necessary
                 bool k0 = false, k1 = false, k2 = false;
                 for (int j = 0; j < sc.n_prims && j < 64; j++) {
                     if (!((ocand >> j) & 1ull)) continue;
@@ -223,7 +250,9 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
             }
 #endif
             RT_LAP(ctr, PF_CHUNK_SHFL);
+#ifndef RT_X_NOFRESH226
             RT_FRESH();
+#endif
             d3 target = d3{L.O.x, L.O.y, L.O.z};
             if (act) {
                 if (!point) {
@@ -252,6 +281,10 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
                 }
             }
         }
+#if defined(RT_UTIL_COUNTERS) && RT_X_OUTCOME
+        if (heavy && !STRICT) ctr.u[6]++, ctr.u[7] += (cnt == n_l), ctr.u[8] += (cnt == 0), ctr.u[9] += (uint32_t)cnt, ctr.u[10] += (uint32_t)n_l;
+        if (work && !heavy && !STRICT) ctr.u[11] += (cnt == n_l);
+#endif
         RT_LAP(ctr, PF_CHUNK_SHFL);
         RT_FRESH();
         if (need && dt > RT_EPS) {
@@ -311,7 +344,7 @@ DEV d3 ld_frame_acc(const uint32_t* fl, int k) {
 #ifndef RT_FRAME_LDS
 #define RT_FRAME_LDS 2
 #endif
-template <bool STRICT, bool SHARE, int FLDS>
+template <bool STRICT, bool SHARE, int FLDS, bool CONE>
 DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* xch, uint32_t* fl) {
     // The launch parameters and the scene record are read from the kernel-argument segment where they are needed, through a
     // pointer the compiler has to take as new at the start of every stage (RT_FRESH): otherwise all ~100 words of them are
@@ -432,7 +465,7 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);
         RT_FRESH();
-        if (mask != 0ull) local = diffusion_coop<STRICT, SHARE>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk, xch);
+        if (mask != 0ull) local = diffusion_coop<STRICT, SHARE, CONE>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk, xch);
 
         RT_FRESH();
         if (tracing) {
@@ -586,7 +619,10 @@ __global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams) {
     constexpr int XCH_WORDS = RT_SHARE_CLOSEST ? 448 : 192;
     __shared__ __attribute__((aligned(8))) uint32_t s_xch[SHARE ? 4 * XCH_WORDS : 2];
     uint32_t* xch = SHARE ? s_xch + (threadIdx.x >> 6) * XCH_WORDS : nullptr;
-    trace_stream<STRICT, SHARE, FLDS>(P, shade, ctr, stk, xch, fl);
+    // the look down the meshes' trees before shadow rays are dealt (mesh_cone_may): in the build for mesh-heavy scenes only.
+    // Elsewhere it saves less than the registers it takes cost (c4_lucy 35.0 -> 36.3 ms/frame with it, c5_final 137 -> 118).
+    constexpr bool CONE = !STRICT && RT_CONE_WALK && WAVES == 4;
+    trace_stream<STRICT, SHARE, FLDS, CONE>(P, shade, ctr, stk, xch, fl);
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_REFILL);
     if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);

@@ -149,46 +149,20 @@ DEV int rank_in(unsigned long long mask) {  // number of set bits of `mask` belo
 }
 DEV double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 DEV d3 shfl_d3(d3 v, int src) { return d3{__shfl(v.x, src, 64), __shfl(v.y, src, 64), __shfl(v.z, src, 64)}; }
-// Bitwise OR over the lanes that are active at the call (which may be any subset: divergent call sites are fine), the same value
-// in every lane and held in scalar registers.  All 64 lanes are switched on for the reduction, the ones that were off
-// contributing 0: three exchanges inside each quad / half row / row of 16 lanes leave every lane with the OR of its row, and
-// the four rows are read out by lane.  (Two wait states lie between a vector write and a DPP read of the same register: the
-// two words are interleaved and one s_nop added.)
+// Bitwise OR over the wave, the same value in every lane and held in scalar registers.  Call it with all 64 lanes active
+// (lanes with nothing to contribute pass 0): the exchanges go through fixed partner lanes, and a partner that is switched
+// off passes nothing on.  Three exchanges inside each quad / half row / row of 16 lanes leave every lane with the OR of its
+// row; the four rows are read out by lane.
+DEV uint32_t wave_or_u32(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);  // row_mirror
+    return ((uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16)) |
+           ((uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48));
+}
 DEV unsigned long long wave_or_u64(unsigned long long v) {
-    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    uint32_t a, b, a0, a1, a2, a3, b0, b1, b2, b3;
-    unsigned long long was;
-    asm volatile(
-        "s_or_saveexec_b64 %[was], -1\n\t"
-        "v_cndmask_b32_e64 %[a], 0, %[lo], %[was]\n\t"
-        "v_cndmask_b32_e64 %[b], 0, %[hi], %[was]\n\t"
-        "s_nop 0\n\t"
-        "v_or_b32_dpp %[a], %[a], %[a] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_or_b32_dpp %[b], %[b], %[b] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_or_b32_dpp %[a], %[a], %[a] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_or_b32_dpp %[b], %[b], %[b] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_or_b32_dpp %[a], %[a], %[a] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "v_or_b32_dpp %[b], %[b], %[b] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_or_b32_dpp %[a], %[a], %[a] row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "v_or_b32_dpp %[b], %[b], %[b] row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_readlane_b32 %[a0], %[a], 0\n\t"
-        "v_readlane_b32 %[a1], %[a], 16\n\t"
-        "v_readlane_b32 %[a2], %[a], 32\n\t"
-        "v_readlane_b32 %[a3], %[a], 48\n\t"
-        "v_readlane_b32 %[b0], %[b], 0\n\t"
-        "v_readlane_b32 %[b1], %[b], 16\n\t"
-        "v_readlane_b32 %[b2], %[b], 32\n\t"
-        "v_readlane_b32 %[b3], %[b], 48\n\t"
-        "s_mov_b64 exec, %[was]"
-        : [a] "=&v"(a), [b] "=&v"(b), [was] "=&s"(was), [a0] "=&s"(a0), [a1] "=&s"(a1), [a2] "=&s"(a2), [a3] "=&s"(a3),
-          [b0] "=&s"(b0), [b1] "=&s"(b1), [b2] "=&s"(b2), [b3] "=&s"(b3)
-        : [lo] "v"(lo), [hi] "v"(hi)
-        : "scc");
-    return ((unsigned long long)((b0 | b1) | (b2 | b3)) << 32) | ((a0 | a1) | (a2 | a3));
+    return ((unsigned long long)wave_or_u32((uint32_t)(v >> 32)) << 32) | wave_or_u32((uint32_t)v);
 }
 DEV unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll

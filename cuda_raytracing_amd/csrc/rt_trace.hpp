@@ -1136,37 +1136,127 @@ DEV double seg_seg_dist2(d3 p1, d3 q1, d3 p2, d3 q2, double& s_out, double& t_ou
     return dot(g, g);
 }
 
+// ---- can a mesh stand between a point and a lamp at all? ----------------------------------------------
+// Every shadow segment from A to a point T of the lamp (|T - Lc| <= Rl, D = Lc - A), continued to parameter smax, lies in
+//     { A + s D + e : 0 <= s <= smax, |e| <= s Rl },
+// and such a point can be inside a box [lo, hi] only if, on every axis k, lo_k - s Rl <= A_k + s D_k <= hi_k + s Rl: two
+// half-lines in s per axis.  The walk below goes down the mesh's four-wide tree with that test (single precision, boxes and
+// bounds padded by far more than the rounding errors, constraints whose slope is too close to zero left out - leaving one out
+// only widens the answer) and answers "may" as soon as a box RT_CONE_LEVELS levels down, or a triangle's box, passes it;
+// "cannot" only when no such box is left.  A mesh that cannot is dropped from the point's candidates for this lamp, and a
+// point without candidates has every sample visible without a ray being traced.  Most points near a mesh's bounding box
+// are not near the mesh (c5_final: four out of five points that had to trace shadow rays because of a mesh's root box found
+// every sample visible).  `stk` = this lane's traversal stack (free while candidates are collected).
+#ifndef RT_CONE_WALK
+#define RT_CONE_WALK 1
+#endif
+#ifndef RT_CONE_LEVELS
+#define RT_CONE_LEVELS 5
+#endif
+#ifndef RT_CONE_STEPS
+#define RT_CONE_STEPS 48  // interior nodes looked at before the walk gives up and answers "may"
+#endif
+#ifdef RT_X_CONE_NOINLINE
+static __device__ __attribute__((noinline))
+#else
+DEV
+#endif
+bool mesh_cone_may(SCREF sc, const DevGeom RT_CONST& g, d3 A, d3 D, double Rl, double smax, uint32_t* stk) {
+    uint32_t ref = (uint32_t)(g.aux2 - 1);
+    const float S = (float)g.f[MSH_SCALE];
+    const float Af[3] = {(float)A.x, (float)A.y, (float)A.z}, Df[3] = {(float)D.x, (float)D.y, (float)D.z};
+    const float R = (float)Rl * 1.00001f + 1e-30f, sm = (float)smax * 1.0001f;
+    const float reach = S + fabsf(Af[0]) + fabsf(Af[1]) + fabsf(Af[2]);
+    if (!(reach + sm * (fabsf(Df[0]) + fabsf(Df[1]) + fabsf(Df[2]) + R) < 1e30f)) return true;  // (also NaN)
+    const float pad = 2e-6f * reach + 1e-30f;
+    // per axis: the plane that bounds s from below (m_n, k_n) and the one that bounds it from above (m_f, k_f)
+    float m_n[3], k_n[3], m_f[3], k_f[3];
+    uint32_t o_n[3], o_f[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const bool up = Df[k] >= 0.0f;
+        const float thr = 1e-2f * (fabsf(Df[k]) + R) + 1e-30f;
+        // entering: s (D_k + R) >= lo - A going up, s (D_k - R) <= hi - A going down (slope of the same sign as D_k, never small
+        // unless both are); leaving: s (D_k - R) <= hi - A going up, s (D_k + R) >= lo - A going down: bounds s from above
+        // only where the cone grows more slowly than its axis moves
+        const float a_n = up ? Df[k] + R : Df[k] - R, a_f = up ? Df[k] - R : Df[k] + R;
+        const float p_n = up ? Af[k] + pad : Af[k] - pad, p_f = up ? Af[k] - pad : Af[k] + pad;
+        const bool has_n = fabsf(a_n) > thr, has_f = up ? a_f > thr : a_f < -thr;
+        m_n[k] = has_n ? 1.0f / a_n : 0.0f, k_n[k] = has_n ? -(p_n * m_n[k]) : -__builtin_inff();
+        m_f[k] = has_f ? 1.0f / a_f : 0.0f, k_f[k] = has_f ? -(p_f * m_f[k]) : __builtin_inff();
+        o_n[k] = (up ? 0u : 48u) + 16u * (uint32_t)k, o_f[k] = (up ? 48u : 0u) + 16u * (uint32_t)k;
+    }
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const char* nbase = reinterpret_cast<const char*>(sc.nodes4);
+    int sp = 0, level = 0, steps = 0;
+    if (ref & RT_REF_LEAF) return true;
+    for (;;) {
+        const uint32_t nb = ref * (uint32_t)sizeof(DevNode4);
+        const f4 nx = *reinterpret_cast<const f4*>(nbase + (nb + o_n[0])), ny = *reinterpret_cast<const f4*>(nbase + (nb + o_n[1])),
+                 nz = *reinterpret_cast<const f4*>(nbase + (nb + o_n[2]));
+        const f4 fx = *reinterpret_cast<const f4*>(nbase + (nb + o_f[0])), fy = *reinterpret_cast<const f4*>(nbase + (nb + o_f[1])),
+                 fz = *reinterpret_cast<const f4*>(nbase + (nb + o_f[2]));
+        const u4 ch = *reinterpret_cast<const u4*>(nbase + (nb + 96u));
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float lo_s = fmaxf(fmaxf(__builtin_fmaf(nx[c], m_n[0], k_n[0]), __builtin_fmaf(ny[c], m_n[1], k_n[1])), __builtin_fmaf(nz[c], m_n[2], k_n[2]));
+            const float hi_s = fminf(fminf(__builtin_fmaf(fx[c], m_f[0], k_f[0]), __builtin_fmaf(fy[c], m_f[1], k_f[1])), __builtin_fmaf(fz[c], m_f[2], k_f[2]));
+            // (written so that a NaN passes)
+            const bool ok = ch[c] != RT_REF_END && !(lo_s > hi_s + fabsf(hi_s) * 2e-4f + 1e-30f) && !(hi_s < 0.0f) && !(lo_s > sm);
+            if (ok) {
+                if ((ch[c] & RT_REF_LEAF) || level + 1 >= RT_CONE_LEVELS || ch[c] >= (1u << 24) || sp >= RT_STACK) return true;
+                stk[sp * 64] = ch[c] | (uint32_t)(level + 1) << 24, sp++;
+            }
+        }
+        if (sp == 0) return false;
+        if (++steps >= RT_CONE_STEPS) return true;
+        const uint32_t e = stk[(--sp) * 64];
+        ref = e & 0xFFFFFFu, level = (int)(e >> 24);
+    }
+}
+
 #ifndef RT_CONE_MESH_PASSES
 #define RT_CONE_MESH_PASSES 2
 #endif
 #ifndef RT_CONE_BALL
 #define RT_CONE_BALL 1
 #endif
-// `full` gets the primitives that, each on its own, hide the whole lamp from A (spheres and cylinders only: the
-// point lies in their umbra, every sample is occluded, none needs tracing).
-DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, int lamp, unsigned long long skip,
-                                        unsigned long long& full) {
+// The grid's answer for the cell A lies in: the primitives that may stand between its points and the lamp (all of them where
+// the grid has no answer), less `skip`; `full` gets those that hide the whole lamp from every point of the cell.
+DEV unsigned long long candidate_cell(SCREF sc, d3 A, int lamp, unsigned long long skip, unsigned long long& full) {
     full = 0ull;
-    if (sc.n_prims > 64) return ~0ull;
-    // the cell's mask first: most points have nothing near their way to the lamp, and the rest only a few primitives
     unsigned long long cell = ~0ull;
-    if (sc.cand_grid) {
+    if (sc.n_prims <= 64 && sc.cand_grid) {
         const double gx = (A.x - sc.cg_lo[0]) * sc.cg_inv[0], gy = (A.y - sc.cg_lo[1]) * sc.cg_inv[1], gz = (A.z - sc.cg_lo[2]) * sc.cg_inv[2];
         if (gx >= 0.0 && gy >= 0.0 && gz >= 0.0 && gx < (double)RT_CGRID && gy < (double)RT_CGRID && gz < (double)RT_CGRID) {
             const int ix = (int)gx, iy = (int)gy, iz = (int)gz;
             const ulonglong2 cm = reinterpret_cast<const ulonglong2*>(sc.cand_grid)[(((size_t)lamp * RT_CGRID + iz) * RT_CGRID + iy) * RT_CGRID + ix];
-            cell = cm.x & ~skip;
-            if ((cm.y & ~skip) != 0ull) {  // the whole cell lies in the umbra of one primitive
-                full = cm.y;
-                return cell;
-            }
+            cell = cm.x;
+            full = cm.y & ~skip;
         }
     }
-    if (cell == 0ull) return 0ull;
+    return cell & ~skip;
+}
+
+// radius of the ball around L.O that holds every sample point of the lamp, rounded up
+DEV double lamp_reach(const rt_light RT_CONST& L) {
     double Rl = 0.0;
     if (L.type == RT_LIGHT_SPHERE) Rl = fabs(L.R);
     else if (L.type == RT_LIGHT_SQUARE) Rl = module(d3{L.Dx.x, L.Dx.y, L.Dx.z}) + module(d3{L.Dy.x, L.Dy.y, L.Dy.z});
-    Rl = Rl * (1.0 + 1e-6) + 1e-9;
+    return Rl * (1.0 + 1e-6) + 1e-9;
+}
+
+// The primitives that may stand between A and the lamp, for a point whose cell mask is `cell` (candidate_cell; the caller has
+// dealt with cells in an umbra).  `wave_cells` = the union of `cell` over the lanes that call (the same in every lane): only those
+// primitives are looked at.  `full` gets the primitives that, each on its own, hide the whole lamp from A (spheres and cylinders
+// only: the point lies in their umbra, every sample is occluded, none needs tracing).
+DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt_light RT_CONST& L, unsigned long long skip,
+                                        unsigned long long cell, unsigned long long wave_cells, unsigned long long& full) {
+    full = 0ull;
+    if (sc.n_prims > 64) return ~0ull;
+    if (cell == 0ull) return 0ull;
+    const double Rl = lamp_reach(L);
     const d3 Lc = d3{L.O.x, L.O.y, L.O.z}, D = Lc - A;
     const double L2 = dot(D, D);
     if (!(L2 > 1e-200) || !(L2 < 1e200) || !(Rl < 1e100)) return ~0ull;
@@ -1183,14 +1273,9 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
 #pragma unroll
     for (int k = 0; k < 3; k++) iD[k] = fabs(Da[k]) > 1e-200 ? approx_rcp(Da[k]) : 0.0;
     unsigned long long m = 0;
-    // only the primitives in some lane's cell mask are looked at (the lanes that are here: the call site is divergent)
-#ifdef RT_X_LC
-    for (int j = 0; j < sc.n_prims; j++) {
-#else
     const unsigned long long in_scene = sc.n_prims >= 64 ? ~0ull : (1ull << sc.n_prims) - 1ull;
-    for (unsigned long long todo = wave_or_u64(cell) & in_scene; todo != 0ull; todo &= todo - 1ull) {
+    for (unsigned long long todo = wave_cells & in_scene; todo != 0ull; todo &= todo - 1ull) {
         const int j = __builtin_ctzll(todo);
-#endif
         if (__ballot(((cell >> j) & 1ull) != 0ull && (full & ~skip) == 0ull) == 0ull) continue;  // no lane still needs this primitive
         const DevGeom RT_CONST& g = GEOM(sc)[j];
         bool may = ((cell >> j) & 1ull) != 0ull;

@@ -226,8 +226,36 @@ def test_shadow_walk_variants_give_the_same_image(monkeypatch):
         images.append(img)
         rays.append((s.rays, s.rays_shadow_traced))
     assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
-    assert rays[0] == rays[1] == rays[2]
-    assert 0 < rays[0][1] < s.rays_shadow
+    # (the rays a render has to trace differ between the builds: the shared variant of this scene is the four-wave build,
+    # which drops points no mesh can shadow before dealing their rays)
+    assert rays[0][0] == rays[1][0] == rays[2][0] and rays[1] == rays[2]
+    assert 0 < rays[1][1] <= rays[0][1] < s.rays_shadow
+
+
+@pytest.mark.parametrize("name,W,H,focal,aperture", [("c4_lucy", 320, 180, 1.35, 1.0), ("c5_final", 256, 144, 168.0, 150.0)])
+@pytest.mark.parametrize("preset", ["gpu_ref", "cpu_ref"])
+def test_builds_for_three_and_four_waves_give_the_same_image(monkeypatch, name, W, H, focal, aperture, preset):
+    """The kernel build for mesh-heavy scenes (four waves per SIMD) looks down the meshes' trees before it deals shadow rays
+    and drops the points no mesh can shadow; the other build does not.  Both must render the reference-order image bit for
+    bit, under both presets (they differ in how far a mesh's shadow reaches: RT_F_MESH_RAW_DIR), the first with fewer rays."""
+    hs = scene(name)
+    flags = abi.RT_MODE_GPU_REF if preset == "gpu_ref" else abi.RT_MODE_CPU_REF
+    st_strict = orc.settings(spp=3, dof=True, focal=focal, aperture=aperture, seed=11, flags=flags | abi.RT_F_STRICT_TRAVERSAL)
+    st_fast = orc.settings(spp=3, dof=True, focal=focal, aperture=aperture, seed=11, flags=flags)
+    traced = {}
+    strict = None
+    for waves in ("3", "4"):
+        monkeypatch.setenv("RT_AMD_WAVES", waves)
+        with device_scene(hs) as ds:
+            if strict is None:
+                strict, sstats = ds.render_frame(st_strict, W, H)
+            fast, fstats = ds.render_frame(st_fast, W, H)
+        assert np.array_equal(fast, strict), f"{name} {preset}: the {waves}-wave build differs from the reference-order image"
+        assert fstats.rays == sstats.rays and fstats.shaded_hits == sstats.shaded_hits
+        traced[waves] = fstats.rays_shadow_traced
+    assert 0 < traced["4"] <= traced["3"] < sstats.rays_shadow, traced
+    if preset == "gpu_ref":  # (sampled lamps: the look down the trees has points to drop)
+        assert traced["4"] < traced["3"], traced
 
 
 def test_many_overlapping_meshes_shared_plain_and_strict_agree(tmp_path, monkeypatch):

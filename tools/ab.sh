@@ -10,6 +10,6 @@ for v in "$@"; do
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        j = json.loads(line); print('$v', '$CFG', 'ms_per_step', round(j['ms_per_step'], 2), 'kernel_ms', round(j['roofline']['kernel_ms_avg'], 2))
+        j = json.loads(line); print('$v', '$CFG', 'ms_per_step', round(j['ms_per_step'], 2), 'kernel_ms', round(j['roofline']['kernel_ms_avg'], 2), 'traced_Mrays', round(j['rays_traced_per_frame'] / 1e6, 1))
 " >> $LOG || exit 1
 done
