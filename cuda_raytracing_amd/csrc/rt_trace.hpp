@@ -1219,6 +1219,9 @@ bool mesh_cone_may(SCREF sc, const DevGeom RT_CONST& g, d3 A, d3 D, double Rl, d
 #ifndef RT_CONE_MESH_PASSES
 #define RT_CONE_MESH_PASSES 2
 #endif
+#ifndef RT_CONE_SQUARE
+#define RT_CONE_SQUARE 1
+#endif
 #ifndef RT_CONE_BALL
 #define RT_CONE_BALL 1
 #endif
@@ -1363,6 +1366,36 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
                 // cone's surface is |e| cos(a) - (distance along the axis) sin(a) = |e| cos(a) - spu * Rl
                 const double q = rb * (1.0 + 1e-6) + 1e-9 * (1.0 + len) + spu * Rl;
                 if (ee * cos2_a > q * q * (1.0 + 1e-9)) may = false;
+            }
+            if (RT_CONE_SQUARE && may && g.type == RT_PRIM_SQUARE) {
+                // A square fills little of its bounding ball.  A shadow segment A + s (D + e), |e| <= Rl, meets the square's plane
+                // where hA + s (hL - hA + N.e) = 0 (hA, hL: heights of A and of the lamp's centre over the plane): not at all
+                // if A and the whole lamp lie on one side, else for s between hA / (hA - hL -+ Rl); there its coordinates
+                // along Dx, Dy (CR/Collision.cu:219-224 compares |(P - O).Dx| with Dx.Dx) lie within s Rl |Dx| of the axis point's.
+                const d3 O = G3(g, SQR_O), N = G3(g, SQR_N);
+                const double hA = dot(A - O, N), hL = dot(Lc - O, N);
+                const double tol = 1e-7 * (1.0 + fabs(hA) + fabs(hL));
+                if ((hA > tol && hL > Rl + tol) || (hA < -tol && hL < -(Rl + tol))) {
+                    may = false;
+                } else {
+                    const double dlo = (hA - hL) - Rl, dhi = (hA - hL) + Rl;
+                    if (dlo > tol || dhi < -tol) {  // (else some segments run along the plane: no bound on s)
+                        const double s1 = hA / dlo, s2 = hA / dhi;
+                        const double slo = fmax(fmin(s1, s2) * (1.0 - 1e-9) - 1e-9, 0.0), shi = fmin(fmax(s1, s2) * (1.0 + 1e-9) + 1e-9, 1.0 + 1e-9);
+                        if (slo > shi) {
+                            may = false;  // the plane is met before A or beyond the lamp
+                        } else {
+                            const d3 w0 = A - O, Dx = G3(g, SQR_DX), Dy = G3(g, SQR_DY);
+                            const double lx = g.f[SQR_LX], ly = g.f[SQR_LY];
+                            const double uA = dot(w0, Dx), uD = dot(D, Dx), vA = dot(w0, Dy), vD = dot(D, Dy);
+                            const double ru = shi * Rl * sqrt(lx), rv = shi * Rl * sqrt(ly);
+                            const double u1 = uA + slo * uD, u2 = uA + shi * uD, v1 = vA + slo * vD, v2 = vA + shi * vD;
+                            const double eu = 1e-9 * (lx + fabs(uA) + fabs(uD)) + 1e-12, ev = 1e-9 * (ly + fabs(vA) + fabs(vD)) + 1e-12;
+                            if (fmin(u1, u2) - ru > lx + eu || fmax(u1, u2) + ru < -(lx + eu) || fmin(v1, v2) - rv > ly + ev || fmax(v1, v2) + rv < -(ly + ev))
+                                may = false;
+                        }
+                    }
+                }
             }
         }
         if (may) m |= 1ull << j;
