@@ -132,7 +132,7 @@ DEV uint32_t to_u8(double c) {
 
 // ---- CalnDiffusion for every lane that needs it, shadow rays dealt over the wave ---------------
 // CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
-template <bool STRICT, bool SHARE, bool CONE>
+template <bool STRICT, bool SHARE, bool CONE, bool MESH4>
 DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
                       uint32_t pixel, uint32_t smp, Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const RenderParams RT_CONST* pp;
@@ -267,7 +267,7 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
             if (SHARE && stk != nullptr) {
                 clear = shadow_clear_shared(sc, P.flags, act, C, target, ocand, chunk_prims, ctr, stk, xch);
             } else if (act) {
-                clear = shadow_clear<STRICT>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, chunk_prims, ctr, stk);
+                clear = shadow_clear<STRICT, MESH4>(sc, P.flags, C, target, crashed, L.light_primitive, ocand, chunk_prims, ctr, stk);
             }
             RT_LAP(ctr, PF_SH_PRIMS);
             const unsigned long long cm = __ballot(clear);
@@ -344,7 +344,10 @@ DEV d3 ld_frame_acc(const uint32_t* fl, int k) {
 #ifndef RT_FRAME_LDS
 #define RT_FRAME_LDS 2
 #endif
-template <bool STRICT, bool SHARE, int FLDS, bool CONE>
+#ifndef RT_FRAME_LDS_LEAN
+#define RT_FRAME_LDS_LEAN 4  // in the kernels without traversal stacks
+#endif
+template <bool STRICT, bool SHARE, int FLDS, bool CONE, bool MESH4>
 DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t* stk, uint32_t* xch, uint32_t* fl) {
     // The launch parameters and the scene record are read from the kernel-argument segment where they are needed, through a
     // pointer the compiler has to take as new at the start of every stage (RT_FRESH): otherwise all ~100 words of them are
@@ -445,7 +448,7 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
         RT_FRESH();
         if (tracing && sp + 1 <= RT_MAX_DEPTH) {
             if (sp > 0) ctr.rays_secondary++;
-            h = scene_closest<STRICT, false>(sc, P.flags, o, d, ctr, nullptr, 0, no_log, stk, RT_SHARE_CLOSEST && SHARE ? xch : nullptr);
+            h = scene_closest<STRICT, false, MESH4>(sc, P.flags, o, d, ctr, nullptr, 0, no_log, stk, RT_SHARE_CLOSEST && SHARE ? xch : nullptr);
             if (h.prim < 0) {
                 d3 c = unit(d);
                 double t = 0.5 * (((P.flags & RT_F_SKY_Y) ? c.y : c.z) + 1.0);
@@ -465,7 +468,7 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
         d3 local = D3(0, 0, 0);
         const unsigned long long mask = __ballot(need_shade);
         RT_FRESH();
-        if (mask != 0ull) local = diffusion_coop<STRICT, SHARE, CONE>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk, xch);
+        if (mask != 0ull) local = diffusion_coop<STRICT, SHARE, CONE, MESH4>(P, shade, mask, need_shade, h, draw, pixel, smp, ctr, stk, xch);
 
         RT_FRESH();
         if (tracing) {
@@ -586,15 +589,18 @@ DEV void trace_stream(RPREF P_in, const DevShade* shade, Counters& ctr, uint32_t
 // walking meshes dominate, because that loop waits on dependent node loads (c5_final at 32 spp: 182 -> 169 ms/frame).
 template <bool STRICT, int SHADE_CAP, bool SHARE, int WAVES = RT_WAVES_PER_SIMD>
 __global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams) {
-    // frames kept in LDS: only where three blocks still fit a CU's 160 KB with them (small shading table, three-waves build)
-    constexpr int FLDS = (!STRICT && SHADE_CAP == 16 && WAVES == 3) ? RT_FRAME_LDS : 0;
+    // The kernels with an LDS shading table and per-lane shadow walks are launched only for scenes in which no mesh has a
+    // four-wide tree (launch_tiles): the four-wide walks and their LDS stacks are left out of them.
+    constexpr bool MESH4 = !STRICT && (SHARE || SHADE_CAP == 0);
+    // frames kept in LDS: only where three blocks still fit a CU's 160 KB with them (small shading table and three-waves build, or no stacks)
+    constexpr int FLDS = STRICT ? 0 : (SHADE_CAP > 0 && !MESH4) ? RT_FRAME_LDS_LEAN : (SHADE_CAP == 16 && WAVES == 3) ? RT_FRAME_LDS : 0;
     __shared__ uint32_t s_frames[FLDS > 0 ? 4 * FLDS * 7 * 64 : 1];
     uint32_t* fl = FLDS > 0 ? s_frames + (threadIdx.x >> 6) * (FLDS * 7 * 64) + (threadIdx.x & 63) : nullptr;
     RPREF P = KERNARG(RenderParams);
     const int lane = lane_id();
     // per-lane traversal stacks of the block's four waves: [wave][entry][lane]
-    __shared__ uint32_t s_stack[STRICT ? 1 : 4 * RT_STACK_ROWS * 64];
-    uint32_t* stk = STRICT ? nullptr : s_stack + (threadIdx.x >> 6) * (RT_STACK_ROWS * 64) + lane;
+    __shared__ uint32_t s_stack[MESH4 ? 4 * RT_STACK_ROWS * 64 : 1];
+    uint32_t* stk = MESH4 ? s_stack + (threadIdx.x >> 6) * (RT_STACK_ROWS * 64) + lane : nullptr;
     __shared__ DevShade s_shade[SHADE_CAP > 0 ? SHADE_CAP : 1];
     const DevShade* shade = P.sc.shade;
     if (SHADE_CAP > 0) {  // every hit reads a few fields of its record, one after another
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(256, WAVES) void render_kernel(RenderParams) {
     // the look down the meshes' trees before shadow rays are dealt (mesh_cone_may): in the build for mesh-heavy scenes only.
     // Elsewhere it saves less than the registers it takes cost (c4_lucy 35.0 -> 36.3 ms/frame with it, c5_final 137 -> 118).
     constexpr bool CONE = !STRICT && RT_CONE_WALK && WAVES == 4;
-    trace_stream<STRICT, SHARE, FLDS, CONE>(P, shade, ctr, stk, xch, fl);
+    trace_stream<STRICT, SHARE, FLDS, CONE, MESH4>(P, shade, ctr, stk, xch, fl);
 #ifdef RT_UTIL_COUNTERS
     RT_LAP(ctr, PF_REFILL);
     if (lane < PF_COUNT) atomicAdd(&P.counters[CTR_ALL + lane], ctr.prof[1 + lane]);
@@ -1182,6 +1188,7 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
     P.queue = ws.queue, P.out = dst, P.counters = ws.counters, P.path_out = ws.path_out;
 
     const bool share = !strict && s->shared_walk == 1;
+    const bool tree4 = s->dev.mesh_scale_max > 0.0;  // some mesh has a four-wide tree
     // one launch: the blocks [first, first + nb) of the list, traced and resolved
     auto launch = [&](uint64_t first, uint64_t nb) -> int {
         P.blocks = ws.blocks + first, P.n_blocks = (uint32_t)nb, P.n_paths = (uint32_t)(nb * block_paths);
@@ -1220,9 +1227,10 @@ static int launch_tiles(rt_scene* s, Workspace& ws, const rt_settings* st, int t
         if (strict) hipLaunchKernelGGL((render_kernel<true, 0, false>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= 16 && four) hipLaunchKernelGGL((render_kernel<false, 16, true, 4>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= 16 && share) hipLaunchKernelGGL((render_kernel<false, 16, true>), g, t, 0, g_stream, P);
-        else if (P.sc.n_prims <= 16) hipLaunchKernelGGL((render_kernel<false, 16, false>), g, t, 0, g_stream, P);
+        // (per-lane shadow walks and a four-wide tree - only under RT_AMD_SHARED_WALK=0 - go to the general kernel below)
+        else if (P.sc.n_prims <= 16 && !tree4) hipLaunchKernelGGL((render_kernel<false, 16, false>), g, t, 0, g_stream, P);
         else if (P.sc.n_prims <= RT_SHADE_LDS && share) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS, true>), g, t, 0, g_stream, P);
-        else if (P.sc.n_prims <= RT_SHADE_LDS) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS, false>), g, t, 0, g_stream, P);
+        else if (P.sc.n_prims <= RT_SHADE_LDS && !tree4) hipLaunchKernelGGL((render_kernel<false, RT_SHADE_LDS, false>), g, t, 0, g_stream, P);
         else hipLaunchKernelGGL((render_kernel<false, 0, false>), g, t, 0, g_stream, P);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, g_stream, P);

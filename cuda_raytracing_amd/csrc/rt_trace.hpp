@@ -1038,7 +1038,8 @@ DEV void mesh_fill_hit(SCREF sc, uint32_t leafref, d3 o, d3 d, double t0, Hit& h
 }
 
 // ---- closest hit over the scene: CR/Scene.cu:3-21, CR/Scene.cpp:27-38 ---------------------
-template <bool STRICT, bool LOG>
+// MESH4 = false: built for scenes in which no mesh has a four-wide tree (the per-lane stack `stk` is then unused and may be null)
+template <bool STRICT, bool LOG, bool MESH4 = true>
 DEV Hit scene_closest(SCREF sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint32_t* log, uint32_t log_cap,
                       uint32_t& log_n, uint32_t* stk, uint32_t* xch = nullptr) {
     Hit best;
@@ -1071,9 +1072,9 @@ DEV Hit scene_closest(SCREF sc, uint32_t flags, d3 o, d3 d, Counters& ctr, uint3
             case RT_PRIM_TRIANGLE: t = triangle_hit<true>(g, o, dm, tmp); break;
             case RT_PRIM_MESH: {
                 RT_LAP(ctr, PF_CLOSEST_PRIMS);
-                MeshResult r = (!STRICT && g.aux2 && stk && xch)
+                MeshResult r = (!STRICT && MESH4 && g.aux2 && stk && xch)
                                    ? mesh_closest_shared(sc, g, o, dm, lim, ctr, stk, xch)
-                               : (!STRICT && g.aux2 && stk)
+                               : (!STRICT && MESH4 && g.aux2 && stk)
                                    ? mesh_walk4<false>(sc, g, o, dm, lim, ctr, stk)
                                    : mesh_walk<STRICT, false, LOG>(sc, g.aux0, o, dm, lim, g.f[MSH_SCALE], ctr, log, log_cap, log_n,
                                                                    (uint32_t)g.aux1 << 24);
@@ -1408,7 +1409,7 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
 // `cand` = the primitives this ray has to be tested against (pruned mode, scenes of at most 64 primitives: the shaded one and the
 // lamp's own are already left out of it), `wave_prims` = the union of `cand` over the rays of the wave (the same in every lane):
 // the loop visits only those.  Reference-order mode and scenes of more than 64 primitives test every primitive but the skipped.
-template <bool STRICT>
+template <bool STRICT, bool MESH4 = true>
 DEV bool shadow_clear(SCREF sc, uint32_t flags, d3 C, d3 target, int crashed, int light_prim, unsigned long long cand,
                       unsigned long long wave_prims, Counters& ctr, uint32_t* stk) {
     const d3 Vv = target - C;
@@ -1452,7 +1453,7 @@ DEV bool shadow_clear(SCREF sc, uint32_t flags, d3 C, d3 target, int crashed, in
             case RT_PRIM_TRIANGLE: t = triangle_hit<false>(g, C, dm, tmp); break;
             case RT_PRIM_MESH:
                 RT_LAP(ctr, PF_SH_PRIMS);
-                t = (!STRICT && g.aux2 && stk) ? mesh_walk4<true>(sc, g, C, dm, dist, ctr, stk).t
+                t = (!STRICT && MESH4 && g.aux2 && stk) ? mesh_walk4<true>(sc, g, C, dm, dist, ctr, stk).t
                                                : mesh_walk<STRICT, true, false>(sc, g.aux0, C, dm, dist, g.f[MSH_SCALE], ctr, nullptr, 0, dummy_n, 0).t;
                 RT_LAP(ctr, PF_SH_MESH);
                 break;
