@@ -133,7 +133,7 @@ DEV uint32_t to_u8(double c) {
 // ---- CalnDiffusion for every lane that needs it, shadow rays dealt over the wave ---------------
 // CR/Scene_Material.cu:29-66 + CR/Shade.cu:23-113.  Must be called by all 64 lanes.
 template <bool STRICT, bool SHARE, bool CONE, bool MESH4>
-DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
+DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade_tbl, unsigned long long mask, bool need, const Hit& h, uint32_t& draw,
                       uint32_t pixel, uint32_t smp, Counters& ctr, uint32_t* stk, uint32_t* xch) {
     const RenderParams RT_CONST* pp;
     RT_FRESH();
@@ -142,11 +142,9 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
 #define L (LIGHTS(sc)[l])  // the lamp's record, read where it lies
     const int lane = lane_id();
     d3 color = D3(0, 0, 0), ret = D3(0, 0, 0);
-    double m_diff = 0.0, m_spec = 0.0;
     if (need) {
-        const DevShade& m = shade[h.prim];
+        const DevShade& m = shade_tbl[h.prim];
         color = D3(m.color);
-        m_diff = m.diff, m_spec = m.spec;
         if (m.texture >= 0) color = mulv(color, texture_color(sc, P.flags, m, h, ctr));
         ctr.shaded++;
     }
@@ -291,6 +289,8 @@ DEV d3 diffusion_coop(RPREF P_in, const DevShade* shade, unsigned long long mask
             double shade = point ? (cnt ? 1.0 : 0.0) : (double)cnt / n_l;
             if (!(shade < RT_EPS)) {
                 const d3 Lc = d3{L.color.x, L.color.y, L.color.z};
+                // (the coefficients are read from the table again for every lamp: two registers fewer alive across the shadow rays)
+                const double m_diff = shade_tbl[h.prim].diff, m_spec = shade_tbl[h.prim].spec;
                 if (m_diff > RT_EPS) {
                     double diff = m_diff * dt * shade;
                     ret = ret + mulv(color, Lc) * diff;
