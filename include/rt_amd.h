@@ -263,7 +263,8 @@ double rt_scene_tree_build_ms(const rt_scene* scene);
  * at rt_scene_create from the scene's contents: scenes with meshes get the shared variant (it is faster
  * wherever shadow rays walk meshes, and as fast elsewhere).  Returns the choice (0 = plain, 1 = shared);
  * the two times are always 0 (nothing is timed).  RT_AMD_SHARED_WALK=0|1 in the environment overrides
- * the rule.  No counterpart in the reference. */
+ * the rule (with 0 a scene whose meshes have four-wide trees renders with the general kernel: per-lane walks,
+ * shading table in global memory).  No counterpart in the reference. */
 int rt_scene_shared_walk(const rt_scene* scene, double* plain_ms, double* shared_ms);
 /* The shared variant is built twice, for three and for four resident waves per SIMD (168 / 128 registers per lane).  Four pays
  * only where shadow rays walking meshes carry the frame; scenes with several meshes or more than 65536 triangles get it
