@@ -5,7 +5,8 @@ renders them with (semantics preset gpu_ref, seed 1): headline = c4_lucy 1920x10
 34 bands of 8 rows spread evenly over the frame (rows 64 k + 24 .. 64 k + 31; the whole frame would take the oracle an hour).  Every ray is traced in reference order (minutes on 8 cores), so the ray / node /
 triangle totals of a frame are the reference's.  Writes tests/golden/render/<scene>_<height>p<spp>.npz: the 8-bit image
 (R, G, B planes, row 0 = bottom) and the counters.
-Usage: python tools/make_fullframe_golden.py [--config headline|c2|c3|c5x4|c5|c4bands] [--threads N]"""
+c4 = the whole 3840x2160x32 frame (over an hour as well).
+Usage: python tools/make_fullframe_golden.py [--config headline|c2|c3|c5x4|c5|c4bands|c4] [--threads N]"""
 import argparse
 import os
 import sys
@@ -53,14 +54,15 @@ def bands(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c5x4", "c5", "c4bands"])
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c5x4", "c5", "c4bands", "c4"])
     args = ap.parse_args()
     if args.config == "c4bands":
         return bands(args)
     name, W, H, spp, aperture, focal = {"headline": ("c4_lucy", 1920, 1080, 32, 1.0, 1.35), "c2": ("c2_textured_mirror", 1280, 720, 128, 10.0, 10.2),
                                         "c3": ("c3_orange", 1920, 1080, 64, 10.0, 14.5),
                                         "c5x4": ("c5_final", 1920, 1080, 4, 150.0, 168.0),  # C5's frame at 4 of its 128 samples
-                                        "c5": ("c5_final", 1920, 1080, 128, 150.0, 168.0)}[args.config]  # the whole of C5: about 75 minutes on 8 cores
+                                        "c5": ("c5_final", 1920, 1080, 128, 150.0, 168.0),  # the whole of C5: about 75 minutes on 8 cores
+                                        "c4": ("c4_lucy", 3840, 2160, 32, 1.0, 1.35)}[args.config]  # the whole of C4: about 70 minutes on 8 cores
     args.out = os.path.join(ROOT, "tests", "golden", "render", f"{name}_{H}p{spp}.npz")
     hs = HostScene(os.path.join(SCENE_DIR, name + ".txt"))
     st = orc.settings(spp=spp, dof=True, focal=focal, aperture=aperture, seed=1, flags=abi.RT_MODE_GPU_REF | abi.RT_F_STRICT_TRAVERSAL)
