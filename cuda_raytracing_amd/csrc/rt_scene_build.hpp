@@ -568,7 +568,7 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                             // a point A' + s (T - A') of a shadow segment (|A' - A| <= rho, |T - Lc| <= Rl) lies within
                             // |1 - s| rho + s Rl of A + s D: clip with the largest such radius, then again with the
                             // largest radius inside the overlap found
-                            const double smax = (len + rho + Rl) * (1.0 + 1e-6), pad = 1e-9 * (1.0 + g.f[MSH_SCALE]);
+                            const double smax = (len + rho + Rl) * (1.0 + 1e-6), pad = 1e-9 * (1.0 + g.f[MSH_SCALE] + std::fabs(A.x) + std::fabs(A.y) + std::fabs(A.z));
                             double rc = smax * (Rl + rho) + pad;
                             const double Aa[3] = {A.x, A.y, A.z}, Da[3] = {D.x, D.y, D.z};
                             for (int pass = 0; pass < 3 && may; pass++) {
@@ -602,13 +602,15 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                             sp = std::fmin(std::fmax(sp, 0.0), smax);
                             const h3 e = w - D * sp;
                             const double rr = g.f[BND_R] + rc;
-                            if (hdot(e, e) > rr * rr * (1.0 + 1e-9)) may = false;
+                            // clear of the intersectors' own rounding noise (isect_noise in rt_trace.hpp), for every point of the cell
+                            const double noise = 1e-13 * 2.0 * ((hmodule(w) + rho) * (hmodule(w) + rho) + g.f[BND_R] * g.f[BND_R]);
+                            if (hdot(e, e) > rr * rr * (1.0 + 1e-9) + noise) may = false;
                             if (may && (g.type == RT_PRIM_CYLINDER || g.type == RT_PRIM_BEZIER) && g.f[CAP_R] < 1e100) {
                                 const double reach = g.f[CAP_R] + Rl + rho + 1e-9 * (1.0 + len);
                                 const h3 P0{g.f[CAP_P0], g.f[CAP_P0 + 1], g.f[CAP_P0 + 2]}, P1{g.f[CAP_P1], g.f[CAP_P1 + 1], g.f[CAP_P1 + 2]};
                                 double ss, tt;
                                 const double dd2 = host_seg_seg_dist2(A, Lc, P0, P1, ss, tt);
-                                if (dd2 > reach * reach * (1.0 + 1e-6)) may = false;
+                                if (dd2 > reach * reach * (1.0 + 1e-6) + noise) may = false;
                                 if (may && g.type == RT_PRIM_CYLINDER) {  // umbra of the cylinder for every point of the cell (see light_candidates)
                                     const double Rc = g.f[CAP_R] * (1.0 - 2e-6) - 2e-9, alen = g.f[CYL_LEN];
                                     const double mrg = Rl + rho + 1e-5 * (1.0 + alen + Rc);
@@ -617,15 +619,15 @@ static void build_cand_grid(const rt_scene_desc* d, const std::vector<DevGeom>& 
                                     const h3 ea = a0 - ax * ta;
                                     const double far = std::sqrt(std::fmax(hdot(a0, a0), hdot(a1, a1))) + rho;
                                     const double lim = len - rho - Rl - 2e-6 - g.f[CAP_R], deep = Rc - Rl - rho - 1e-6;
-                                    if (tt * alen > mrg && (1.0 - tt) * alen > mrg && deep > 0.0 && dd2 < deep * deep * (1.0 - 1e-6) && lim > 0.0 && far < lim * (1.0 - 1e-6) &&
-                                        std::sqrt(hdot(ea, ea)) - rho > (g.f[CAP_R] + 2e-6) * (1.0 + 1e-6))
+                                    if (tt * alen > mrg && (1.0 - tt) * alen > mrg && deep > 0.0 && dd2 + noise < deep * deep * (1.0 - 1e-6) && lim > 0.0 && far < lim * (1.0 - 1e-6) &&
+                                        std::sqrt(hdot(ea, ea)) - rho > (g.f[CAP_R] + 2e-6) * (1.0 + 1e-6) + std::sqrt(noise))
                                         full = true;
                                 }
                             }
                             if (may && g.type == RT_PRIM_SPHERE) {  // umbra of the sphere for every point of the cell
                                 const double rb = g.f[BND_R], r_lo = rb * (1.0 - 2e-6) - 2e-9, dA = hmodule(w);
                                 const double dline = std::sqrt(hdot(e, e)) + Rl + rho;
-                                if (r_lo * r_lo - dline * dline > 2e-6 * (1.0 + r_lo * r_lo) && dline < r_lo && dA + rho + rb < len - rho - Rl - 2e-6 && dA - rho - rb > 2e-6)
+                                if (r_lo * r_lo - dline * dline > 2e-6 * (1.0 + r_lo * r_lo) + noise && dline < r_lo && dA + rho + rb < len - rho - Rl - 2e-6 && dA - rho - rb > 2e-6)
                                     full = true;
                             }
                         }

@@ -158,14 +158,24 @@ enum { PF_REFILL = 0, PF_FRAME, PF_CLOSEST_PRIMS, PF_CLOSEST_MESH, PF_SHADE_SETU
 
 DEV d3 G3(const DevGeom RT_CONST& g, int i) { return d3{g.f[i], g.f[i + 1], g.f[i + 2]}; }
 
+// The reference's intersectors compare squared lengths built from (ray origin - primitive), so their rounding error grows with
+// the square of that distance: for a ray that starts 1e5 away from a cylinder of radius 0.1 the quadratic of CR/Collision.cu:3-107
+// is off by ~1e-5 in the squared distances it compares, more than the 1e-6 relative margins of the bounding volumes, and what
+// it reports for a grazing ray is noise.  Every test that predicts an intersector's answer from geometry (bounding balls and
+// capsules, umbra tests) therefore keeps this much clear of the boundary: 1e-13 (~450 units of double rounding) times the squared
+// distance between origin and primitive.  (Found by the randomised scenes: a ray from a wall sphere of radius 1e5 towards a lamp
+// behind a thin cylinder.)
+DEV double isect_noise(double dist2) { return 1e-13 * dist2; }
+
 // Conservative pre-test: false only if the ray (unit direction V) certainly misses the ball, or
 // the ball lies wholly behind the origin, or (t_max given) wholly beyond t_max.  The ball is
-// inflated on the host, so "certainly" holds with rounding to spare; primitives that fail it
-// report "no hit" exactly as their full test would.
+// inflated on the host and the comparisons keep clear of the intersectors' own rounding noise, so
+// primitives that fail it report "no hit" exactly as their full test would.
 DEV bool ball_may_hit(const DevGeom RT_CONST& g, d3 o, d3 V, double t_max) {
     d3 P = o - G3(g, BND_C);
     double r = g.f[BND_R];
     double b = -dot(P, V), pp = dot(P, P), r2 = r * r;
+    r2 = r2 + isect_noise(pp + r2);  // the squared radius, widened by the intersectors' rounding noise at this distance
     double disc = b * b - pp + r2;
     if (disc < 0) return false;
     if (b < 0 && pp > r2) return false;
@@ -1324,7 +1334,7 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
             // segment A + D*s, 0 <= s <= smax, against the root box grown by the radius of the region; the cone
             // is narrower than the capsule near A, so the radius is lowered to the cone's at the far end of the
             // overlap found so far and the clip repeated
-            const double smax = raw ? s_raw : 1.0, pad = 1e-9 * (1.0 + g.f[MSH_SCALE]);
+            const double smax = raw ? s_raw : 1.0, pad = 1e-9 * (1.0 + g.f[MSH_SCALE] + fabs(A.x) + fabs(A.y) + fabs(A.z));
             double rc = (raw ? r_raw : Rl) + pad, thi = smax;
 #pragma unroll
             for (int pass = 0; pass < RT_CONE_MESH_PASSES && may; pass++) {
@@ -1354,7 +1364,10 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
             const double spu = dot(w, D) * inv, sp = fmin(fmax(spu, 0.0), smax);
             const d3 e = w - D * sp;
             const double rb = g.f[BND_R], rr = rb + rc, ee = dot(e, e);
-            if (ee > rr * rr * (1.0 + 1e-9)) may = false;
+            // (2 (|w|^2 + rb^2) bounds the squared distance from A to any point of the primitive; taken afresh at each use: one
+            // register pair fewer alive across the tests)
+#define noise isect_noise(2.0 * (dot(w, w) + rb * rb))
+            if (ee > rr * rr * (1.0 + 1e-9) + noise) may = false;
             if (g.type == RT_PRIM_SPHERE) {
                 // a sphere around the whole capsule: every shadow ray starts and ends inside it and meets its surface
                 // only beyond the lamp sample, which is no occlusion (CR/Shade.cu:75: dist - hit.dist > 1e-6)
@@ -1368,7 +1381,7 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
                 const d3 P0 = G3(g, CAP_P0), P1 = G3(g, CAP_P1);
                 double ss, tt;
                 const double dd2 = seg_seg_dist2(A, Lc, P0, P1, ss, tt);
-                if (dd2 > reach * reach * (1.0 + 1e-6)) may = false;
+                if (dd2 > reach * reach * (1.0 + 1e-6) + noise) may = false;
                 if (may && g.type == RT_PRIM_CYLINDER) {
                     // Umbra of the solid cylinder: the axis of the shadow rays passes so deep inside it (radially and away
                     // from both ends) that every ray to the lamp goes through its interior, all of it lies nearer than the
@@ -1381,8 +1394,8 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
                     const double far2 = fmax(dot(a0, a0), dot(a1, a1));
                     const double lim = len - Rl - 2e-6 - g.f[CAP_R];
                     const double deep = Rc - Rl - 1e-6;
-                    if (tt * alen > m && (1.0 - tt) * alen > m && deep > 0.0 && dd2 < deep * deep * (1.0 - 1e-6) && lim > 0.0 &&
-                        far2 < lim * lim * (1.0 - 1e-6) && dot(ea, ea) > (g.f[CAP_R] + 2e-6) * (g.f[CAP_R] + 2e-6) * (1.0 + 1e-6))
+                    if (tt * alen > m && (1.0 - tt) * alen > m && deep > 0.0 && dd2 + noise < deep * deep * (1.0 - 1e-6) && lim > 0.0 &&
+                        far2 < lim * lim * (1.0 - 1e-6) && dot(ea, ea) > (g.f[CAP_R] + 2e-6) * (g.f[CAP_R] + 2e-6) * (1.0 + 1e-6) + noise)
                         full |= 1ull << j;
                 }
             }
@@ -1391,13 +1404,13 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
                 // (with 1e-6 to spare in the discriminant), the sphere lies wholly in front of the lamp, A wholly outside
                 const double r_lo = rb * (1.0 - 2e-6) - 2e-9, dA2 = dot(w, w);
                 const double dA = dA2 * approx_rsqrt(fmax(dA2, 1e-300)), dline = ee * approx_rsqrt(fmax(ee, 1e-300)) + Rl;
-                if (r_lo * r_lo - dline * dline > 2e-6 * (1.0 + r_lo * r_lo) && dA + rb < len - Rl - 2e-6 && dA - rb > 2e-6) full |= 1ull << j;
+                if (r_lo * r_lo - dline * dline > 2e-6 * (1.0 + r_lo * r_lo) + noise && dA + rb < len - Rl - 2e-6 && dA - rb > 2e-6) full |= 1ull << j;
             }
             if (RT_CONE_BALL && cone && spu > 0.0 && spu <= smax) {
                 // beside the segment: e is the offset of the ball's centre from the axis, and its distance from the
                 // cone's surface is |e| cos(a) - (distance along the axis) sin(a) = |e| cos(a) - spu * Rl
                 const double q = rb * (1.0 + 1e-6) + 1e-9 * (1.0 + len) + spu * Rl;
-                if (ee * cos2_a > q * q * (1.0 + 1e-9)) may = false;
+                if (ee * cos2_a > q * q * (1.0 + 1e-9) + noise) may = false;
             }
             if (RT_CONE_SQUARE && may && g.type == RT_PRIM_SQUARE) {
                 // A square fills little of its bounding ball.  A shadow segment A + s (D + e), |e| <= Rl, meets the square's plane
@@ -1430,6 +1443,7 @@ DEV unsigned long long light_candidates(SCREF sc, uint32_t flags, d3 A, const rt
                 }
             }
         }
+#undef noise
         if (may) m |= 1ull << j;
     }
     return m;

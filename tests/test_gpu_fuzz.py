@@ -132,59 +132,84 @@ def _keep(path, seed, why):
         g.write(f"# {why}\n" + f.read())
 
 
-def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
+def check_scene(path, seed, with_oracle, waves4=None):
+    """One scene, with the settings that go with its seed: None if the pruned render equals the reference-order render (and, on
+    request, the oracle's), else what differs."""
     from cuda_raytracing_amd.device import DeviceScene
+    hs = HostScene(path, asset_dir=os.path.join(ROOT, "assets"))
+    flags = abi.RT_MODE_GPU_REF if seed % 3 else abi.RT_MODE_CPU_REF
+    if seed % 5 == 0:
+        flags &= ~abi.RT_F_BEZIER_STACKED
+    if seed % 7 == 0:
+        flags ^= abi.RT_F_MESH_RAW_DIR
+    st = orc.settings(spp=SPP, dof=bool(seed % 2), focal=9.0, aperture=1.0, seed=seed + 1, flags=flags | abi.RT_F_STRICT_TRAVERSAL)
+    # the pruned walk's trees from each of the three builders in turn (scenes without meshes have none)
+    # (the builder turns over with seed // 3, the preset with seed % 3, the oracle sample every 13th scene: every preset meets
+    # every builder, and the oracle sees all of those pairs)
+    # every other pair of scenes gets the kernel build for mesh-heavy scenes where the library has one for it (four waves
+    # per SIMD; it alone looks down the meshes' trees before dealing shadow rays): the rule would pick it for none of these
+    if (seed // 2) % 2 if waves4 is None else waves4:
+        os.environ["RT_AMD_WAVES"] = "4"
+    try:
+        ds_cm = DeviceScene(hs, device=0, tree_builder=("host", "device_sah", "device")[(seed // 3) % 3])
+    finally:
+        os.environ.pop("RT_AMD_WAVES", None)
+    with ds_cm as ds:
+        ds.check_trees()
+        strict, ss = ds.render_frame(st, W, H)
+        st.flags = flags
+        fast, fs = ds.render_frame(st, W, H)
+    why = None
+    if not np.array_equal(fast, strict):
+        bad = np.argwhere((fast != strict).any(-1))
+        why = f"pruned image differs from the reference-order image at {len(bad)} pixels, first {bad[0].tolist()}"
+    else:
+        for k in ("rays_primary", "rays_secondary", "rays_shadow", "shaded_hits", "texture_fetches", "pixels"):
+            if getattr(fs, k) != getattr(ss, k):
+                why = f"{k}: pruned {getattr(fs, k)} != reference-order {getattr(ss, k)}"
+        if fs.rays_shadow_traced > fs.rays_shadow or ss.rays_shadow_traced != ss.rays_shadow:
+            why = "traced shadow rays inconsistent"
+    if why is None and with_oracle:  # both GPU modes could be wrong together
+        st.flags = flags | abi.RT_F_STRICT_TRAVERSAL
+        ref, _, os_ = orc.render(hs, st, W, H)
+        d = np.abs(strict[..., :3].astype(int) - ref[..., :3].astype(int))
+        if d.max() > 1 or (d.max(-1) > 0).mean() > 0.01:
+            why = f"reference-order image differs from the oracle: max {d.max()} levels, {(d.max(-1) > 0).mean():.3%} of pixels"
+        elif ss.rays != os_.rays or ss.nodes_visited != os_.nodes_visited or ss.tris_tested != os_.tris_tested:
+            why = f"counters differ from the oracle: rays {ss.rays} vs {os_.rays}, nodes {ss.nodes_visited} vs {os_.nodes_visited}"
+    return why
+
+
+def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
     failures = []
     checked_oracle = 0
     for seed in range(FIRST_SEED, FIRST_SEED + N_SCENES):
         if seed % 100 == 0:
             print(f"fuzz: seed {seed}, {len(failures)} failures so far", flush=True)  # visible with -s: a soak run must not look hung
         path = make_scene(seed, str(tmp_path))
-        hs = HostScene(path, asset_dir=os.path.join(ROOT, "assets"))
-        flags = abi.RT_MODE_GPU_REF if seed % 3 else abi.RT_MODE_CPU_REF
-        if seed % 5 == 0:
-            flags &= ~abi.RT_F_BEZIER_STACKED
-        if seed % 7 == 0:
-            flags ^= abi.RT_F_MESH_RAW_DIR
-        st = orc.settings(spp=SPP, dof=bool(seed % 2), focal=9.0, aperture=1.0, seed=seed + 1, flags=flags | abi.RT_F_STRICT_TRAVERSAL)
-        # the pruned walk's trees from each of the three builders in turn (scenes without meshes have none)
-        # (the builder turns over with seed // 3, the preset with seed % 3, the oracle sample every 13th scene: every preset meets
-        # every builder, and the oracle sees all of those pairs)
-        # every other pair of scenes gets the kernel build for mesh-heavy scenes where the library has one for it (four waves
-        # per SIMD; it alone looks down the meshes' trees before dealing shadow rays): the rule would pick it for none of these
-        if (seed // 2) % 2:
-            os.environ["RT_AMD_WAVES"] = "4"
-        try:
-            ds_cm = DeviceScene(hs, device=0, tree_builder=("host", "device_sah", "device")[(seed // 3) % 3])
-        finally:
-            os.environ.pop("RT_AMD_WAVES", None)
-        with ds_cm as ds:
-            ds.check_trees()
-            strict, ss = ds.render_frame(st, W, H)
-            st.flags = flags
-            fast, fs = ds.render_frame(st, W, H)
-        why = None
-        if not np.array_equal(fast, strict):
-            bad = np.argwhere((fast != strict).any(-1))
-            why = f"pruned image differs from the reference-order image at {len(bad)} pixels, first {bad[0].tolist()}"
-        else:
-            for k in ("rays_primary", "rays_secondary", "rays_shadow", "shaded_hits", "texture_fetches", "pixels"):
-                if getattr(fs, k) != getattr(ss, k):
-                    why = f"{k}: pruned {getattr(fs, k)} != reference-order {getattr(ss, k)}"
-            if fs.rays_shadow_traced > fs.rays_shadow or ss.rays_shadow_traced != ss.rays_shadow:
-                why = "traced shadow rays inconsistent"
-        if why is None and seed % 13 == 0:  # the oracle on a sample: both GPU modes could be wrong together
-            st.flags = flags | abi.RT_F_STRICT_TRAVERSAL
-            ref, _, os_ = orc.render(hs, st, W, H)
-            d = np.abs(strict[..., :3].astype(int) - ref[..., :3].astype(int))
-            if d.max() > 1 or (d.max(-1) > 0).mean() > 0.01:
-                why = f"reference-order image differs from the oracle: max {d.max()} levels, {(d.max(-1) > 0).mean():.3%} of pixels"
-            elif ss.rays != os_.rays or ss.nodes_visited != os_.nodes_visited or ss.tris_tested != os_.tris_tested:
-                why = f"counters differ from the oracle: rays {ss.rays} vs {os_.rays}, nodes {ss.nodes_visited} vs {os_.nodes_visited}"
-            checked_oracle += 1
+        why = check_scene(path, seed, with_oracle=seed % 13 == 0)
+        checked_oracle += seed % 13 == 0
         if why:
             _keep(path, seed, why)
             failures.append((seed, why))
     abi.load_library().rt_set_tree_builder(0)
     assert not failures, f"{len(failures)} of {N_SCENES} scenes failed (scene files kept in gpurun_out/fuzz_fail_<seed>.txt): {failures[:5]}"
     assert checked_oracle >= N_SCENES // 13
+
+
+REGRESS = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden", "fuzz_regress")) if f.startswith("seed_") and f.endswith(".txt"))
+
+
+@pytest.mark.parametrize("name", REGRESS)
+def test_scenes_a_soak_run_once_failed_on(name):
+    """Scenes of soak runs (RT_FUZZ_SCENES / RT_FUZZ_FIRST_SEED) on which the pruned render once differed, kept as written by the
+    generator, with both kernel builds and against the oracle.  seed_33674: a ray leaves a wall sphere of radius 1e5 towards a point
+    lamp behind a thin cylinder and grazes the cylinder 2e-5 inside its surface; at that distance the reference's quadratic
+    (CR/Collision.cu:3-107) carries more rounding error than that and reports a miss, while the umbra test of the shadow candidates,
+    which reasons about exact geometry with 1e-6 margins, declared the lamp hidden.  The tests that predict an intersector's answer
+    now keep clear of its rounding noise (isect_noise)."""
+    seed = int(name[len("seed_"):-len(".txt")])
+    path = os.path.join(ROOT, "tests", "golden", "fuzz_regress", name)
+    for waves4 in (False, True):
+        why = check_scene(path, seed, with_oracle=not waves4, waves4=waves4)
+        assert why is None, (name, waves4, why)
