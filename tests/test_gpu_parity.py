@@ -500,10 +500,7 @@ def test_other_configs_at_full_size(name, W, H, spp, aperture, focal, blocks):
     # every configuration has the CPU oracle's own full frame committed (tools/make_fullframe_golden.py; minutes of the oracle for
     # C2 / C3, over an hour each for C4 and C5): every pixel, the ray / shading totals of the frame and, for the mesh scenes, the
     # node and triangle totals of the reference-order traversal
-    fixture = os.path.join(GOLD, "render", f"{name}_{H}p{spp}.npz")
-    if meshes and not os.path.exists(fixture):  # FIXTURE-PENDING
-        return
-    g = np.load(fixture)
+    g = np.load(os.path.join(GOLD, "render", f"{name}_{H}p{spp}.npz"))
     assert (int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])) == (W, H, spp, 1)
     assert float(g["focal"]) == focal and float(g["aperture"]) == aperture and int(g["flags"]) == abi.RT_MODE_GPU_REF
     ref = np.stack([g["r"], g["g"], g["b"], np.full((H, W), 255, np.uint8)], -1)
