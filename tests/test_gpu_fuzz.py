@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 N_SCENES = int(os.environ.get("RT_FUZZ_SCENES", "400"))      # a soak run sets these two: other seeds, more of them
 FIRST_SEED = int(os.environ.get("RT_FUZZ_FIRST_SEED", "0"))
-W, H, SPP = 64, 48, 2
+# (a soak run may also render larger frames with more samples: more and deeper paths per scene)
+W, H, SPP = int(os.environ.get("RT_FUZZ_W", "64")), int(os.environ.get("RT_FUZZ_H", "48")), int(os.environ.get("RT_FUZZ_SPP", "2"))
 
 
 def _v(a):
