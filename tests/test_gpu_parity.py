@@ -309,6 +309,7 @@ def test_three_kernel_render_equals_one_kernel_render(monkeypatch, name, W, H, s
     with device_scene(hs) as ds:
         assert ds.deferred_shadows == (0, 0)
         one, os_ = ds.render_frame(st, W, H)
+        cone_walk = ds.waves_per_simd == 4  # the kernel for mesh-heavy scenes looks down the trees before it deals shadow rays: fewer are traced
     monkeypatch.setenv("RT_AMD_DEFER", "1")
     with device_scene(hs) as ds:
         three, ts = ds.render_frame(st, W, H)
@@ -322,8 +323,10 @@ def test_three_kernel_render_equals_one_kernel_render(monkeypatch, name, W, H, s
     assert np.array_equal(three, one) and np.array_equal(again, one)
     x0, y0, w, h = rect
     assert np.array_equal(part[y0:y0 + h, x0:x0 + w], one[y0:y0 + h, x0:x0 + w])
-    for k in ("rays_primary", "rays_secondary", "rays_shadow", "rays_shadow_traced", "shaded_hits", "texture_fetches", "pixels"):
+    for k in ("rays_primary", "rays_secondary", "rays_shadow", "shaded_hits", "texture_fetches", "pixels"):
         assert getattr(ts, k) == getattr(os_, k) == getattr(as_, k), k
+    assert as_.rays_shadow_traced == os_.rays_shadow_traced  # the fall-back is the one kernel
+    assert ts.rays_shadow_traced >= os_.rays_shadow_traced if cone_walk else ts.rays_shadow_traced == os_.rays_shadow_traced
 
 
 FLAGS = [abi.RT_F_NORMALIZE_PRIMARY, abi.RT_F_SKY_Y, abi.RT_F_TIE_LATER_WINS, abi.RT_F_SHADOW_SELF_SKIP, abi.RT_F_SQUARE_UV_NO_ORIGIN,
