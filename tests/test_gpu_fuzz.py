@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 N_SCENES = int(os.environ.get("RT_FUZZ_SCENES", "400"))      # a soak run sets these two: other seeds, more of them
 FIRST_SEED = int(os.environ.get("RT_FUZZ_FIRST_SEED", "0"))
+ORACLE_EVERY = int(os.environ.get("RT_FUZZ_ORACLE_EVERY", "13"))  # every how many scenes the CPU oracle renders the scene as well
 # (a soak run may also render larger frames with more samples: more and deeper paths per scene)
 W, H, SPP = int(os.environ.get("RT_FUZZ_W", "64")), int(os.environ.get("RT_FUZZ_H", "48")), int(os.environ.get("RT_FUZZ_SPP", "2"))
 
@@ -188,14 +189,14 @@ def test_pruned_render_equals_reference_order_render_on_random_scenes(tmp_path):
         if seed % 100 == 0:
             print(f"fuzz: seed {seed}, {len(failures)} failures so far", flush=True)  # visible with -s: a soak run must not look hung
         path = make_scene(seed, str(tmp_path))
-        why = check_scene(path, seed, with_oracle=seed % 13 == 0)
-        checked_oracle += seed % 13 == 0
+        why = check_scene(path, seed, with_oracle=seed % ORACLE_EVERY == 0)
+        checked_oracle += seed % ORACLE_EVERY == 0
         if why:
             _keep(path, seed, why)
             failures.append((seed, why))
     abi.load_library().rt_set_tree_builder(0)
     assert not failures, f"{len(failures)} of {N_SCENES} scenes failed (scene files kept in gpurun_out/fuzz_fail_<seed>.txt): {failures[:5]}"
-    assert checked_oracle >= N_SCENES // 13
+    assert checked_oracle >= N_SCENES // ORACLE_EVERY
 
 
 REGRESS = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden", "fuzz_regress")) if f.startswith("seed_") and f.endswith(".txt"))
