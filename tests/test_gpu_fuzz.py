@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 N_SCENES = int(os.environ.get("RT_FUZZ_SCENES", "400"))      # a soak run sets these two: other seeds, more of them
 FIRST_SEED = int(os.environ.get("RT_FUZZ_FIRST_SEED", "0"))
+BIG_MESHES = os.environ.get("RT_FUZZ_BIG_MESHES") == "1"  # half of the meshes are the benchmark scenes' large ones (deep trees, long walks)
 ORACLE_EVERY = int(os.environ.get("RT_FUZZ_ORACLE_EVERY", "13"))  # every how many scenes the CPU oracle renders the scene as well
 # (a soak run may also render larger frames with more samples: more and deeper paths per scene)
 W, H, SPP = int(os.environ.get("RT_FUZZ_W", "64")), int(os.environ.get("RT_FUZZ_H", "48")), int(os.environ.get("RT_FUZZ_SPP", "2"))
@@ -102,6 +103,8 @@ def make_scene(seed, tmp):
             f = ["icosa.obj", "boxgrid.obj"][rng.integers(0, 2)]
             rot = rng.normal(0, 0.8, 3) if rng.random() < 0.7 else np.zeros(3)
             s = 0.4 + 1.4 * rng.random()
+            if BIG_MESHES and rng.random() < 0.5:  # the statue (33 k triangles, unit size) or the bunny (69 k, size 0.17)
+                f, s = [("lucy_34k_normalized.rtm", 0.8 + 2.2 * rng.random()), ("bunny_69k.rtm", 8.0 + 20.0 * rng.random())][rng.integers(0, 2)]
             t.append(f"primitive mesh\n O= {_v(c)}\n scale= {s:.3f} {s:.3f} {s:.3f}\n rotation= {_v(rot)}\n file= {f}\n{_material(rng)}end\n")
     for _ in range(rng.integers(1, 4)):
         mode = rng.integers(0, 4)
